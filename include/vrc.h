@@ -1,0 +1,214 @@
+/*
+ * vrc.h -- C ABI of the MI355X-native raycast path ("libvrc.so").
+ *
+ * Drop-in boundary for the reference's CLCaster subsystem
+ * (include/CLCaster.h:93-329, src/CLCaster.cpp).  Every entry point names the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++,
+ * torch, OpenCL or GL types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns a vrc_status (0 = ok); the reference returns
+ *     bool and logs through Logger (CLCaster.cpp:1011-1017).  Details of the
+ *     last failure: vrc_last_error().  Nothing aborts or throws.
+ *   - scene buffers are COPIED at call time (reference: CL_MEM_COPY_HOST_PTR,
+ *     CLCaster.cpp:893-896); camera, lights and light_count are RETAINED
+ *     pointers re-read on every vrc_compute (reference: CL_MEM_USE_HOST_PTR,
+ *     CLCaster.cpp:137-139,322) -- the caller keeps them alive.
+ *   - a handle drives ONE GPU and is not thread-safe (the reference is
+ *     single-threaded).  Multi-GPU = one handle per GPU, each
+ *     rendering its own row tiles (vrc_set_row_tiling); no collective.
+ *   - the GL-shared output texture of the reference (CLCaster.cpp:278-296) is
+ *     replaced by an offline float4 pixel buffer in HBM, read back with
+ *     vrc_read_image_*.
+ */
+#ifndef VRC_H
+#define VRC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrc_caster vrc_caster;
+
+typedef enum vrc_status {
+    VRC_OK = 0,
+    VRC_ERR_INVALID_ARGUMENT = 1,
+    VRC_ERR_NOT_READY = 2,      /* validate()/compute() before the required assign_* calls */
+    VRC_ERR_DEVICE = 3,         /* a HIP call failed; see vrc_last_error */
+    VRC_ERR_OUT_OF_MEMORY = 4,
+    VRC_ERR_NOT_FOUND = 5,      /* unknown setting name */
+    VRC_ERR_LIMIT = 6           /* > 64 settings, octree deeper than the kernel stack, ... */
+} vrc_status;
+
+/* ---- lifecycle ------------------------------------------------------- */
+
+/* CLCaster::CLCaster + CLCaster::init (CLCaster.cpp:14-74).  The interactive
+ * device prompt / device_config.bin (:23-48,495-542) is replaced by
+ * device_ordinal.  Fails with VRC_ERR_DEVICE when no HIP device is present:
+ * there is no CPU fallback.                                                  */
+int vrc_create(int device_ordinal, vrc_caster **out);
+/* CLCaster::~CLCaster (CLCaster.cpp:5-12); unlike the reference this frees all
+ * device memory.                                                            */
+int vrc_destroy(vrc_caster *h);
+/* Logger::log(..., ERROR) + cl_err_lookup (CLCaster.cpp:1112-1310) */
+const char *vrc_last_error(const vrc_caster *h);
+/* aquire_hardware (CLCaster.cpp:430-493): number of usable GPUs */
+int vrc_device_count(int *count);
+
+/* ---- scene buffers (copied) ------------------------------------------- */
+
+/* CLCaster::assign_map (CLCaster.cpp:76-87): "map" char[dx*dy*dz] indexed
+ * x + dx*(y + dz*z) by the kernel (ray_caster_kernel.cl:569), "map_dimensions". */
+int vrc_assign_map(vrc_caster *h, const int8_t *voxels, int32_t dx, int32_t dy, int32_t dz);
+/* CLCaster::release_map (CLCaster.cpp:89-99) */
+int vrc_release_map(vrc_caster *h);
+
+/* CLCaster::assign_octree (CLCaster.cpp:102-116): "octree_descriptor_buffer"
+ * (n 64-bit child descriptors, format of include/map/Octree.h:89-94) and the
+ * "octree_root_index" setting.  The two attachment buffers the reference
+ * uploads but never reads (ray_caster_kernel.cl:143-144) are optional.        */
+int vrc_assign_octree(vrc_caster *h, const uint64_t *descriptors, uint64_t n_descriptors,
+                      uint64_t root_index);
+int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_t n_lookup,
+                                  const uint64_t *attachments, uint64_t n_attachments);
+/* CLCaster::release_octree (CLCaster.cpp:119-131) */
+int vrc_release_octree(vrc_caster *h);
+
+/* CLCaster::create_viewport (CLCaster.cpp:233-299): builds the float4 ray table
+ * exactly like the reference (v_fov / h_fov are accepted and ignored, as there)
+ * and the output image, initialised to RGBA8 (255,255,255,100).              */
+int vrc_create_viewport(vrc_caster *h, int32_t width, int32_t height, float v_fov, float h_fov);
+/* CLCaster::release_viewport (CLCaster.cpp:301-311) */
+int vrc_release_viewport(vrc_caster *h);
+
+/* CLCaster::create_texture_atlas (CLCaster.cpp:208-222): the sf::Texture is
+ * replaced by its RGBA8 pixels.                                              */
+int vrc_create_texture_atlas(vrc_caster *h, const uint8_t *rgba8, int32_t width, int32_t height,
+                             int32_t tile_w, int32_t tile_h);
+
+/* ---- live buffers (retained pointers) --------------------------------- */
+
+/* CLCaster::assign_camera (CLCaster.cpp:133-143): direction = 2 floats
+ * (inclination, azimuth), position = 3 floats.                              */
+int vrc_assign_camera(vrc_caster *h, const float *direction2, const float *position3);
+/* CLCaster::release_camera (CLCaster.cpp:145-155) */
+int vrc_release_camera(vrc_caster *h);
+/* CLCaster::assign_lights (CLCaster.cpp:313-328): packed = 10 floats per light
+ * {rgbi[4], position[3], direction[3]} (include/LightController.h:63-73), 8
+ * reserved slots in the reference; light_count points at the live count.     */
+int vrc_assign_lights(vrc_caster *h, const float *packed, const int32_t *light_count);
+
+/* ---- settings buffer --------------------------------------------------- */
+
+/* CLCaster::add_to_settings_buffer (CLCaster.cpp:1029-1064): appends a slot
+ * (max 64, include/CLCaster.h:303).  `define` is the kernel-side macro name the
+ * reference passes as -D<define>=<slot>; kept for API fidelity.  Names the
+ * kernel understands:
+ *   octree_dimensions  (OCTDIM)            required in SVO mode
+ *   using_octree       (OCTENABLED)        0 => occupancy from the SVO, != 0 => dense map
+ *   octree_root_index  (OCTREE_ROOT_INDEX) set by vrc_assign_octree
+ * extensions (defaults reproduce the reference):
+ *   max_distance (20)  shadow_rays (1)                                        */
+int vrc_setting_add(vrc_caster *h, const char *name, const char *define, int64_t value);
+/* CLCaster::overwrite_setting (CLCaster.cpp:1087-1109) */
+int vrc_setting_set(vrc_caster *h, const char *name, int64_t value);
+int vrc_setting_get(vrc_caster *h, const char *name, int64_t *value);
+
+/* ---- validate / compute ------------------------------------------------ */
+
+/* CLCaster::validate (CLCaster.cpp:157-206): checks that camera, map/octree,
+ * viewport, lights and atlas are present and consistent.  No runtime
+ * compilation happens: the kernels are prebuilt gfx950 code.                 */
+int vrc_validate(vrc_caster *h);
+
+/* CLCaster::compute (CLCaster.cpp:224-228) -> run_kernel (:946-987).
+ * Synchronous like the reference's clFinish (:970).                          */
+int vrc_compute(vrc_caster *h);
+/* Enqueue one frame on the handle's stream without waiting / wait for it.    */
+int vrc_compute_async(vrc_caster *h);
+int vrc_sync(vrc_caster *h);
+
+/* Multi-GPU row tiling: this handle renders only the bands
+ * b with b % world == rank, a band being `band_rows` consecutive image rows
+ * (multiple of 8).  Default rank 0 / world 1 = the whole image.              */
+int vrc_set_row_tiling(vrc_caster *h, int32_t rank, int32_t world, int32_t band_rows);
+
+/* ---- output ------------------------------------------------------------ */
+
+/* CLCaster::draw (CLCaster.cpp:330-332) has no read-back; these replace it.
+ * n_floats / n_bytes / n_int32 are the capacities of the caller's buffers.   */
+int vrc_read_image_f32(vrc_caster *h, float *rgba, size_t n_floats);
+int vrc_read_image_rgba8(vrc_caster *h, uint8_t *rgba, size_t n_bytes);
+/* 8 int32 per pixel: voxel x,y,z of the primary hit (-1 if none), material,
+ * face bits, flags, final step count, canonical descriptor reads.            */
+int vrc_read_hits(vrc_caster *h, int32_t *hits, size_t n_int32);
+#define VRC_HIT_FLAG_WRITTEN     1
+#define VRC_HIT_FLAG_SHADOW_CAST 2
+#define VRC_HIT_FLAG_SHADOW_HIT  4
+#define VRC_HIT_FLAG_OOB_EXIT    8
+
+/* Device pointers of the resident frame buffers (float4[w*h], int32[8*w*h]);
+ * lets a host that owns the GPU (e.g. a torch process) consume the frame
+ * without a PCIe round trip.                                                 */
+int vrc_device_image(vrc_caster *h, void **dev_ptr, size_t *n_bytes);
+
+/* Counters of the most recent frame (device-side, fetched at sync). */
+typedef struct vrc_counters {
+    uint64_t primary_rays;
+    uint64_t shadow_rays;
+    uint64_t descriptor_reads;   /* canonical count, SURVEY 8(d) */
+    uint64_t texel_reads;
+    uint64_t map_reads;
+    uint64_t steps;
+    uint64_t unwritten_pixels;
+    uint64_t reserved;
+} vrc_counters;
+int vrc_get_counters(vrc_caster *h, vrc_counters *out);
+
+/* hipEvent timing of the raycast kernel on the handle's stream, accumulated
+ * since the last reset (replaces GraphTimer "Compute", Application.cpp:151-155). */
+int vrc_timing_reset(vrc_caster *h);
+int vrc_timing_get(vrc_caster *h, uint64_t *n_launches, double *total_kernel_ms);
+
+/* ---- SVO construction (host side) -------------------------------------- */
+
+/* Octree::Generate (src/map/Octree.cpp:13-43,171-323): bottom-up build of the
+ * descriptor array from a dense char[dim^3] grid.  buffer_size == 0 sizes the
+ * array exactly; otherwise the array has buffer_size entries filled from the
+ * end like the reference's fixed 100000-entry buffer (Octree.h:29).
+ * strict_reference != 0 reproduces the reference layout bit for bit including
+ * its far-pointer corner cases; 0 emits the same format with those fixed.
+ * The result is malloc'ed; release with vrc_free.                            */
+int vrc_octree_generate(const int8_t *grid, uint32_t dim, uint64_t buffer_size,
+                        int strict_reference, uint64_t **descriptors,
+                        uint64_t *n_descriptors, uint64_t *root_index);
+
+/* Procedural sparse builder for grids too large to materialise (SURVEY 8d
+ * "shell-terrain"): solid iff h(x,y)-thickness <= z <= h(x,y).  Emits the same
+ * format/layout as vrc_octree_generate on the equivalent dense grid.
+ * height: optional out, int32[dim*dim] (x + dim*y).                          */
+int vrc_scene_shell_terrain(uint32_t depth, uint64_t seed, int32_t thickness,
+                            int strict_reference, uint64_t **descriptors,
+                            uint64_t *n_descriptors, uint64_t *root_index,
+                            int32_t *height);
+/* Dense twin of the above for depth <= 9 (fills char[dim^3] with material 5). */
+int vrc_scene_shell_terrain_dense(uint32_t depth, uint64_t seed, int32_t thickness, int8_t *grid);
+/* Synthetic 256x256-style atlas: texel = hash(x,y) & 0xFFFFFF, alpha 255.    */
+int vrc_scene_atlas(int32_t width, int32_t height, uint8_t *rgba8);
+
+/* Octree::GetVoxel (src/map/Octree.cpp:45-158), the CPU twin of get_oct_vox
+ * (kernels/ray_caster_kernel.cl:140-251), on a host copy of the array:
+ * found, resolution and sub_oct_pos as that traversal leaves them.            */
+int vrc_octree_get_voxel(const uint64_t *descriptors, uint64_t root_index, uint32_t dim,
+                         const int32_t position[3], int32_t *found, int32_t *resolution,
+                         int32_t sub_oct_pos[3]);
+
+void vrc_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,89 @@
+"""Seeded test scenes shared by the CPU and GPU parity tests.
+
+Each scene is a dict of plain numpy inputs for both the oracle (oracle/orc.py)
+and the product (voxel_raycaster_amd.CLCaster).  The application defaults come
+from the reference's src/Application.cpp:35-79.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+APP_LIGHT = np.array([[0.01, 0.01, 0.01, 0.2, 10.0, 10.0, 10.0, -1.0, -1.0, -1.5]], dtype=np.float32)
+
+
+def hash_atlas(w=256, h=256):
+    """256x256 RGBA8 atlas, deterministic, alpha 255 (numpy twin of vrc_scene_atlas is NOT required
+    to match: fixtures store the atlas explicitly)."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.uint64)
+    v = (x * np.uint64(0x9E3779B1) ^ (y * np.uint64(0x85EBCA77))) * np.uint64(0xC2B2AE3D)
+    v ^= v >> np.uint64(15)
+    a = np.zeros((h, w, 4), dtype=np.uint8)
+    a[..., 0] = (v & np.uint64(255)).astype(np.uint8)
+    a[..., 1] = ((v >> np.uint64(8)) & np.uint64(255)).astype(np.uint8)
+    a[..., 2] = ((v >> np.uint64(16)) & np.uint64(255)).astype(np.uint8)
+    a[..., 3] = 255
+    return a
+
+
+def _grid(dim):
+    return np.zeros((dim, dim, dim), dtype=np.int8)  # indexed [z][y][x] -> flat x + dim*(y + dim*z)
+
+
+def app_default():
+    """The reference application's own scene: 16^3 all material 5, camera inside solid."""
+    g = np.full((16, 16, 16), 5, dtype=np.int8)
+    return dict(name="app_default", dim=16, grid=g.reshape(-1), cam_pos=(2.34, 2.5, 7.17), cam_dir=(2.424, 3.141),
+                lights=APP_LIGHT.copy())
+
+
+def floor_pillars(dim=32, seed=3):
+    rng = np.random.default_rng(seed)
+    g = _grid(dim)
+    g[0:3, :, :] = 5                                  # floor: z < 3
+    for _ in range(dim // 2):
+        x, y = rng.integers(2, dim - 2, size=2)
+        hgt = int(rng.integers(4, dim // 2))
+        g[3:3 + hgt, y, x] = 5
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, dim * 0.8, dim * 0.2, dim * 0.9, -1, -1, -1.5]], dtype=np.float32)
+    return dict(name=f"floor_pillars{dim}", dim=dim, grid=g.reshape(-1), cam_pos=(dim * 0.5 + 0.37, 1.41, dim * 0.45 + 0.29),
+                cam_dir=(2.0, 1.5708), lights=lights)
+
+
+def mirror_wall(dim=32):
+    g = _grid(dim)
+    g[0:2, :, :] = 5
+    g[:, dim - 4:dim - 2, :] = 6                      # mirror wall facing -y
+    g[2:10, dim // 2, dim // 3] = 5
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, dim * 0.3, dim * 0.2, dim * 0.8, -1, -1, -1.5]], dtype=np.float32)
+    return dict(name=f"mirror_wall{dim}", dim=dim, grid=g.reshape(-1), cam_pos=(dim * 0.5 + 0.21, 2.43, dim * 0.3 + 0.37),
+                cam_dir=(1.8, 1.5708), lights=lights)
+
+
+def open_sky(dim=32):
+    """Mostly rays leaving the map (fog path) + one block."""
+    g = _grid(dim)
+    g[dim // 2:dim // 2 + 3, dim // 2:dim // 2 + 3, dim // 2:dim // 2 + 3] = 5
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, 3.0, 3.0, dim - 2.0, -1, -1, -1.5]], dtype=np.float32)
+    return dict(name=f"open_sky{dim}", dim=dim, grid=g.reshape(-1), cam_pos=(dim * 0.5 + 0.6, 3.3, dim * 0.5 + 1.2),
+                cam_dir=(1.5708, 1.5708), lights=lights)
+
+
+def axis_aligned(dim=16):
+    """cam_dir.y == 0 makes sin(yaw) == 0: the x == W/2 column has ray.y == 0 and is never written."""
+    g = _grid(dim)
+    g[0:2, :, :] = 5
+    g[:, :, 0:2] = 5
+    return dict(name=f"axis_aligned{dim}", dim=dim, grid=g.reshape(-1), cam_pos=(dim - 3.5, dim * 0.5 + 0.25, dim * 0.5 + 0.4),
+                cam_dir=(1.9, 0.0), lights=APP_LIGHT.copy())
+
+
+def random_sparse(dim=64, density=0.02, seed=11):
+    rng = np.random.default_rng(seed)
+    g = (rng.random((dim, dim, dim)) < density).astype(np.int8) * 5
+    g[0:2, :, :] = 5
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, dim * 0.25, dim * 0.25, dim * 0.75, -1, -1, -1.5]], dtype=np.float32)
+    return dict(name=f"random_sparse{dim}", dim=dim, grid=g.reshape(-1), cam_pos=(dim * 0.5 + 0.37, dim * 0.125 + 0.41, dim * 0.4 + 0.29),
+                cam_dir=(2.0, 1.5708), lights=lights)
+
+
+ALL = [app_default, floor_pillars, mirror_wall, open_sky, axis_aligned, random_sparse]

@@ -1,0 +1,342 @@
+"""voxel-raycaster_amd -- MI355X-native drop-in for the reference's CLCaster path.
+
+Host-side mirror (Python, for tests and bench) of the reference interface
+``class CLCaster`` (include/CLCaster.h:93-329): same method names, argument
+meaning and bool-returning error behaviour, layered over the C ABI of
+``libvrc.so`` (include/vrc.h).  All compute happens in the hand-written gfx950
+kernels inside that library; there is no Python or CPU fallback -- importing
+this package without the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvrc.so")
+
+
+class VrcError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise VrcError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+_u64p = C.POINTER(C.c_uint64)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_i8p = C.POINTER(C.c_int8)
+_H = C.c_void_p
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "primary_rays", "shadow_rays", "descriptor_reads", "texel_reads", "map_reads", "steps",
+        "unwritten_pixels", "reserved")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
+# every symbol include/vrc.h declares, with its signature
+SIGNATURES = {
+    "vrc_create": (C.c_int, [C.c_int, C.POINTER(_H)]),
+    "vrc_destroy": (C.c_int, [_H]),
+    "vrc_last_error": (C.c_char_p, [_H]),
+    "vrc_device_count": (C.c_int, [_i32p]),
+    "vrc_assign_map": (C.c_int, [_H, _i8p, C.c_int32, C.c_int32, C.c_int32]),
+    "vrc_release_map": (C.c_int, [_H]),
+    "vrc_assign_octree": (C.c_int, [_H, _u64p, C.c_uint64, C.c_uint64]),
+    "vrc_assign_octree_attachments": (C.c_int, [_H, C.POINTER(C.c_uint32), C.c_uint64, _u64p, C.c_uint64]),
+    "vrc_release_octree": (C.c_int, [_H]),
+    "vrc_create_viewport": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_float, C.c_float]),
+    "vrc_release_viewport": (C.c_int, [_H]),
+    "vrc_create_texture_atlas": (C.c_int, [_H, _u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "vrc_assign_camera": (C.c_int, [_H, _f32p, _f32p]),
+    "vrc_release_camera": (C.c_int, [_H]),
+    "vrc_assign_lights": (C.c_int, [_H, _f32p, _i32p]),
+    "vrc_setting_add": (C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_int64]),
+    "vrc_setting_set": (C.c_int, [_H, C.c_char_p, C.c_int64]),
+    "vrc_setting_get": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_int64)]),
+    "vrc_validate": (C.c_int, [_H]),
+    "vrc_compute": (C.c_int, [_H]),
+    "vrc_compute_async": (C.c_int, [_H]),
+    "vrc_sync": (C.c_int, [_H]),
+    "vrc_set_row_tiling": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32]),
+    "vrc_read_image_f32": (C.c_int, [_H, _f32p, C.c_size_t]),
+    "vrc_read_image_rgba8": (C.c_int, [_H, _u8p, C.c_size_t]),
+    "vrc_read_hits": (C.c_int, [_H, _i32p, C.c_size_t]),
+    "vrc_device_image": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "vrc_get_counters": (C.c_int, [_H, C.POINTER(Counters)]),
+    "vrc_timing_reset": (C.c_int, [_H]),
+    "vrc_timing_get": (C.c_int, [_H, _u64p, C.POINTER(C.c_double)]),
+    "vrc_octree_generate": (C.c_int, [_i8p, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(_u64p), _u64p, _u64p]),
+    "vrc_scene_shell_terrain": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, C.c_int, C.POINTER(_u64p), _u64p, _u64p, _i32p]),
+    "vrc_scene_shell_terrain_dense": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, _i8p]),
+    "vrc_scene_atlas": (C.c_int, [C.c_int32, C.c_int32, _u8p]),
+    "vrc_octree_get_voxel": (C.c_int, [_u64p, C.c_uint64, C.c_uint32, _i32p, _i32p, _i32p, _i32p]),
+    "vrc_free": (None, [C.c_void_p]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+STATUS = {0: "VRC_OK", 1: "VRC_ERR_INVALID_ARGUMENT", 2: "VRC_ERR_NOT_READY", 3: "VRC_ERR_DEVICE",
+          4: "VRC_ERR_OUT_OF_MEMORY", 5: "VRC_ERR_NOT_FOUND", 6: "VRC_ERR_LIMIT"}
+
+
+def _ptr(a: np.ndarray, ty):
+    return a.ctypes.data_as(ty)
+
+
+# ---------------------------------------------------------------------------
+# scene-side helpers: Octree / Map (src/map/Octree.cpp, src/map/Map.cpp)
+# ---------------------------------------------------------------------------
+class Octree:
+    """Descriptor array + root index (include/map/Octree.h:26-124)."""
+
+    buffer_size = 100000  # Octree.h:29
+
+    def __init__(self, descriptors: np.ndarray, root_index: int, dim: int):
+        self.descriptor_buffer = np.ascontiguousarray(descriptors, dtype=np.uint64)
+        self.root_index = int(root_index)
+        self.dim = int(dim)
+
+    @classmethod
+    def Generate(cls, data: np.ndarray, dim: int, buffer_size: int = 0, strict_reference: bool = True) -> "Octree":
+        """Octree::Generate (src/map/Octree.cpp:13-43).  data: int8[dim^3], x + dim*(y + dim*z)."""
+        data = np.ascontiguousarray(data, dtype=np.int8).reshape(-1)
+        if data.size != dim ** 3:
+            raise VrcError("grid size does not match dim^3")
+        out = _u64p()
+        n = C.c_uint64()
+        root = C.c_uint64()
+        rc = lib.vrc_octree_generate(_ptr(data, _i8p), dim, buffer_size, int(strict_reference),
+                                     C.byref(out), C.byref(n), C.byref(root))
+        if rc != 0:
+            raise VrcError(f"vrc_octree_generate: {STATUS.get(rc, rc)}")
+        arr = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
+        lib.vrc_free(out)
+        return cls(arr, root.value, dim)
+
+    def GetVoxel(self, position):
+        """Octree::GetVoxel (src/map/Octree.cpp:45-158): (found, resolution, sub_oct_pos)."""
+        pos = (C.c_int32 * 3)(*[int(v) for v in position])
+        found = C.c_int32()
+        res = C.c_int32()
+        sub = (C.c_int32 * 3)()
+        rc = lib.vrc_octree_get_voxel(_ptr(self.descriptor_buffer, _u64p), self.root_index, self.dim, pos,
+                                      C.byref(found), C.byref(res), sub)
+        if rc != 0:
+            raise VrcError(f"vrc_octree_get_voxel: {STATUS.get(rc, rc)}")
+        return bool(found.value), int(res.value), tuple(int(v) for v in sub)
+
+
+def shell_terrain(depth: int, seed: int = 1, thickness: int = 2, strict_reference: bool = False,
+                  want_height: bool = True):
+    """Procedural sparse scene of SURVEY 8(d); returns (Octree, height[dim,dim] or None)."""
+    dim = 1 << depth
+    out = _u64p()
+    n = C.c_uint64()
+    root = C.c_uint64()
+    height = np.zeros((dim, dim), dtype=np.int32) if want_height else None
+    rc = lib.vrc_scene_shell_terrain(depth, seed, thickness, int(strict_reference), C.byref(out), C.byref(n),
+                                     C.byref(root), _ptr(height, _i32p) if want_height else None)
+    if rc != 0:
+        raise VrcError(f"vrc_scene_shell_terrain: {STATUS.get(rc, rc)}")
+    arr = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
+    lib.vrc_free(out)
+    return Octree(arr, root.value, dim), height
+
+
+def shell_terrain_dense(depth: int, seed: int = 1, thickness: int = 2) -> np.ndarray:
+    dim = 1 << depth
+    grid = np.zeros(dim ** 3, dtype=np.int8)
+    rc = lib.vrc_scene_shell_terrain_dense(depth, seed, thickness, _ptr(grid, _i8p))
+    if rc != 0:
+        raise VrcError(f"vrc_scene_shell_terrain_dense: {STATUS.get(rc, rc)}")
+    return grid
+
+
+def synthetic_atlas(width: int = 256, height: int = 256) -> np.ndarray:
+    a = np.zeros((height, width, 4), dtype=np.uint8)
+    rc = lib.vrc_scene_atlas(width, height, _ptr(a, _u8p))
+    if rc != 0:
+        raise VrcError(f"vrc_scene_atlas: {STATUS.get(rc, rc)}")
+    return a
+
+
+class Map:
+    """Map (src/map/Map.cpp:5-19): dense ArrayMap + the Octree generated from it."""
+
+    def __init__(self, dimensions: int, data: Optional[np.ndarray] = None, buffer_size: int = 0,
+                 strict_reference: bool = True):
+        self.dimensions = int(dimensions)
+        if data is None:
+            data = np.full(self.dimensions ** 3, 5, dtype=np.int8)  # ArrayMap ctor fills with 5 (ArrayMap.cpp:17-23)
+        self.array_map = np.ascontiguousarray(data, dtype=np.int8).reshape(-1)
+        self.octree = Octree.Generate(self.array_map, self.dimensions, buffer_size, strict_reference)
+
+
+# ---------------------------------------------------------------------------
+# CLCaster (include/CLCaster.h:93-329)
+# ---------------------------------------------------------------------------
+class CLCaster:
+    """Same surface as the reference class; every method returns bool like there."""
+
+    def __init__(self):
+        self._h = _H()
+        self._keep = {}
+        self.last_status = 0
+
+    # -- helpers
+    def _ok(self, rc: int) -> bool:
+        self.last_status = rc
+        return rc == 0
+
+    def last_error(self) -> str:
+        if not self._h:
+            return "not initialised"
+        return lib.vrc_last_error(self._h).decode()
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib.vrc_destroy(self._h)
+                self._h = _H()
+        except Exception:
+            pass
+
+    # -- CLCaster::init (CLCaster.cpp:14-74)
+    def init(self, device_ordinal: int = 0) -> bool:
+        return self._ok(lib.vrc_create(device_ordinal, C.byref(self._h)))
+
+    # -- scene
+    def assign_map(self, map_: "Map | np.ndarray", dims=None) -> bool:
+        if isinstance(map_, Map):
+            data, d = map_.array_map, (map_.dimensions,) * 3
+        else:
+            data, d = np.ascontiguousarray(map_, dtype=np.int8).reshape(-1), tuple(dims)
+        return self._ok(lib.vrc_assign_map(self._h, _ptr(data, _i8p), d[0], d[1], d[2]))
+
+    def release_map(self) -> bool:
+        return self._ok(lib.vrc_release_map(self._h))
+
+    def assign_octree(self, map_: "Map | Octree") -> bool:
+        oct_ = map_.octree if isinstance(map_, Map) else map_
+        buf = oct_.descriptor_buffer
+        return self._ok(lib.vrc_assign_octree(self._h, _ptr(buf, _u64p), buf.size, oct_.root_index))
+
+    def release_octree(self) -> bool:
+        return self._ok(lib.vrc_release_octree(self._h))
+
+    def assign_camera(self, direction: np.ndarray, position: np.ndarray) -> bool:
+        """direction: float32[2] (inclination, azimuth); position: float32[3].  The arrays are
+        retained and re-read at every compute(), like the reference's USE_HOST_PTR buffers."""
+        assert direction.dtype == np.float32 and position.dtype == np.float32
+        self._keep["cam"] = (direction, position)
+        return self._ok(lib.vrc_assign_camera(self._h, _ptr(direction, _f32p), _ptr(position, _f32p)))
+
+    def release_camera(self) -> bool:
+        self._keep.pop("cam", None)
+        return self._ok(lib.vrc_release_camera(self._h))
+
+    def assign_lights(self, packed: np.ndarray, light_count: Optional[np.ndarray] = None) -> bool:
+        """packed: float32[n,10] = rgbi[4], position[3], direction[3] (LightController.h:63-73)."""
+        assert packed.dtype == np.float32
+        if light_count is None:
+            light_count = np.array([packed.reshape(-1, 10).shape[0]], dtype=np.int32)
+        self._keep["lights"] = (packed, light_count)
+        return self._ok(lib.vrc_assign_lights(self._h, _ptr(packed, _f32p), _ptr(light_count, _i32p)))
+
+    def create_viewport(self, width: int, height: int, v_fov: float = 0.0, h_fov: float = 0.0) -> bool:
+        self.viewport_size = (int(width), int(height))
+        return self._ok(lib.vrc_create_viewport(self._h, width, height, v_fov, h_fov))
+
+    def release_viewport(self) -> bool:
+        return self._ok(lib.vrc_release_viewport(self._h))
+
+    def create_texture_atlas(self, rgba8: np.ndarray, tile_dim) -> bool:
+        a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        hgt, wid = a.shape[0], a.shape[1]
+        return self._ok(lib.vrc_create_texture_atlas(self._h, _ptr(a, _u8p), wid, hgt, int(tile_dim[0]), int(tile_dim[1])))
+
+    # -- settings (CLCaster.cpp:1029-1109)
+    def add_to_settings_buffer(self, setting_name: str, define_accessor_name: str, value: int) -> bool:
+        return self._ok(lib.vrc_setting_add(self._h, setting_name.encode(), define_accessor_name.encode(), int(value)))
+
+    def overwrite_setting(self, setting_name: str, value: int) -> bool:
+        return self._ok(lib.vrc_setting_set(self._h, setting_name.encode(), int(value)))
+
+    def get_setting(self, setting_name: str) -> Optional[int]:
+        v = C.c_int64()
+        if not self._ok(lib.vrc_setting_get(self._h, setting_name.encode(), C.byref(v))):
+            return None
+        return int(v.value)
+
+    # -- validate / compute (CLCaster.cpp:157-228)
+    def validate(self) -> bool:
+        return self._ok(lib.vrc_validate(self._h))
+
+    def compute(self) -> bool:
+        return self._ok(lib.vrc_compute(self._h))
+
+    def compute_async(self) -> bool:
+        return self._ok(lib.vrc_compute_async(self._h))
+
+    def sync(self) -> bool:
+        return self._ok(lib.vrc_sync(self._h))
+
+    def set_row_tiling(self, rank: int, world: int, band_rows: int = 8) -> bool:
+        return self._ok(lib.vrc_set_row_tiling(self._h, rank, world, band_rows))
+
+    # -- output (replaces CLCaster::draw, CLCaster.cpp:330-332)
+    def read_image(self) -> np.ndarray:
+        w, h = self.viewport_size
+        out = np.empty((h, w, 4), dtype=np.float32)
+        if not self._ok(lib.vrc_read_image_f32(self._h, _ptr(out, _f32p), out.size)):
+            raise VrcError(self.last_error())
+        return out
+
+    def read_image_rgba8(self) -> np.ndarray:
+        w, h = self.viewport_size
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        if not self._ok(lib.vrc_read_image_rgba8(self._h, _ptr(out, _u8p), out.size)):
+            raise VrcError(self.last_error())
+        return out
+
+    def read_hits(self) -> np.ndarray:
+        w, h = self.viewport_size
+        out = np.empty((h, w, 8), dtype=np.int32)
+        if not self._ok(lib.vrc_read_hits(self._h, _ptr(out, _i32p), out.size)):
+            raise VrcError(self.last_error())
+        return out
+
+    def counters(self) -> dict:
+        c = Counters()
+        if not self._ok(lib.vrc_get_counters(self._h, C.byref(c))):
+            raise VrcError(self.last_error())
+        return c.as_dict()
+
+    def timing_reset(self) -> bool:
+        return self._ok(lib.vrc_timing_reset(self._h))
+
+    def timing(self):
+        n = C.c_uint64()
+        ms = C.c_double()
+        if not self._ok(lib.vrc_timing_get(self._h, C.byref(n), C.byref(ms))):
+            raise VrcError(self.last_error())
+        return int(n.value), float(ms.value)

@@ -1,0 +1,62 @@
+// Kernel-argument block shared by the host layer (vrc_api.cpp) and the gfx950
+// raycast kernels (raycast_kernel.hip).  One struct passed by value: it lands
+// in the kernarg segment / SGPRs, replacing the 16 cl_mem arguments the
+// reference binds by name (src/CLCaster.cpp:186-202).
+#pragma once
+
+#include <stdint.h>
+
+namespace vrc {
+
+constexpr int kTileW = 8;             // one wavefront = one 8x8 pixel tile
+constexpr int kTileH = 8;
+constexpr int kTilesPerBlock = 4;     // 256-thread block = 4 horizontally adjacent tiles (32x8 px)
+constexpr int kBlockThreads = 64 * kTilesPerBlock;
+constexpr int kMaxLevels = 24;        // descriptor levels the LDS stack can hold (dim <= 2^24)
+
+// hit-record flag bits (include/vrc.h VRC_HIT_FLAG_*)
+constexpr int kFlagWritten = 1, kFlagShadowCast = 2, kFlagShadowHit = 4, kFlagOob = 8;
+
+// counters[] slots (device, uint64)
+enum CounterSlot {
+    kCtrPrimary = 0, kCtrShadow, kCtrDesc, kCtrTex, kCtrMap, kCtrSteps, kCtrUnwritten, kCtrCount = 8
+};
+
+struct RaycastParams {
+    // arg 0-1: dense map
+    const int8_t *map;
+    int32_t map_dim[3];
+    // arg 2-3: viewport
+    int32_t width, height;
+    const float *viewport;            // float4[w*h]
+    // arg 8: offline pixel buffer + hit records
+    float *image;                     // float4[w*h]
+    int32_t *hits;                    // int32[8*w*h]
+    // arg 9-11: atlas
+    const uint8_t *atlas;             // RGBA8
+    int32_t atlas_w, atlas_h;
+    int32_t tiles_x, tiles_y;         // atlas_dim / tile_dim (integer division)
+    // arg 12 + settings: SVO
+    const uint64_t *descriptors;
+    uint64_t root_index;
+    int32_t log2_dim;                 // OCTDIM = 1 << log2_dim
+    int32_t svo;                      // using_octree == 0
+    // arg 4-5: camera (trig evaluated once on the host: SURVEY D2)
+    float cam_pos[3];
+    float trig[4];                    // sin(dir.x) cos(dir.x) sin(dir.y) cos(dir.y)
+    // arg 6: light 0
+    float light_rgbi[4];
+    float light_pos[3];
+    // frame constants written by frame_setup_kernel: {bias[3], reads} -- the
+    // pixel-independent get_oct_vox(camera voxel) of ray_caster_kernel.cl:342-354
+    int32_t *frame;
+    int32_t max_distance;
+    int32_t shadow_rays;
+    // row tiling (multi-GPU)
+    int32_t tile_rank, tile_world, band_tiles;   // band_tiles = band_rows / kTileH
+    int32_t blocks_x;                 // ceil(width / 32)
+    int32_t local_tile_rows;          // tile rows this rank renders
+    unsigned long long *counters;
+};
+
+}  // namespace vrc
