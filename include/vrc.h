@@ -81,6 +81,10 @@ int vrc_release_octree(vrc_caster *h);
  * exactly like the reference (v_fov / h_fov are accepted and ignored, as there)
  * and the output image, initialised to RGBA8 (255,255,255,100).              */
 int vrc_create_viewport(vrc_caster *h, int32_t width, int32_t height, float v_fov, float h_fov);
+/* Extension: same buffers as vrc_create_viewport but the float4[width*height]
+ * ray table ("viewport_matrix", CLCaster.cpp:242-275) is supplied by the host,
+ * e.g. a supersampled or differently projected lens.                          */
+int vrc_create_viewport_table(vrc_caster *h, int32_t width, int32_t height, const float *table);
 /* CLCaster::release_viewport (CLCaster.cpp:301-311) */
 int vrc_release_viewport(vrc_caster *h);
 

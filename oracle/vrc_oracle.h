@@ -13,16 +13,22 @@
  * load this library, and only as the checker.  The product (libvrc.so) never
  * links or calls it.
  *
- * PARITY PINNING: the reference ships no tests/golden vectors and its host
- * code needs SFML/OpenCL/GL which this image lacks (unbuildable here without
- * stand-ins, which are not allowed).  The kernel restatement (a3-a6) is pinned
- * against the *reference kernel itself*, compiled unmodified for gfx950 with
- * the image's own OpenCL device libraries and run on an MI355X through the
- * AMD OpenCL runtime (oracle/ref_build.sh, oracle/ref_run.c,
- * tests/golden/ref_*.npz).  The SVO builder restatement (a2) and Ray::Cast
- * (a7) are "parity unpinned" apart from the reference's own self-check
- * (Octree::Validate, src/map/Octree.cpp:329-352) and Ray::Cast's constant
- * known answer; see DESIGN.md.
+ * PARITY UNPINNED.  The reference ships no tests, golden vectors or fixtures
+ * (SURVEY 4), and none of it can execute in this image without writing
+ * stand-ins, which is not allowed: the host code (Octree.cpp, CLCaster.cpp,
+ * Ray.cpp) needs SFML/OpenCL/GL headers and libraries the image lacks, and the
+ * kernel -- which does compile unmodified for gfx950 with the image's own
+ * OpenCL device libraries -- has no observable output on an MI355X because
+ * CDNA4 has no image hardware: read_imagef/write_imagef lower to no-ops and
+ * the AMD OpenCL runtime refuses clCreateImage (CL_INVALID_OPERATION); evidence
+ * in profiles/r01_reference_kernel_on_gfx950.txt.  This file is therefore a
+ * line-by-line restatement (each block cites the reference line it follows)
+ * checked by (a) the reference's own self-check Octree::Validate
+ * (src/map/Octree.cpp:329-352), (b) a second, independently written builder
+ * in the product (bit-identical output), (c) Ray::Cast's constant known
+ * answer, (d) array-branch == SVO-occupancy equality on the same grid.
+ * tests/golden/orc_*.npz are regression vectors produced by THIS oracle, not
+ * by the reference.  See DESIGN.md "Oracle and pinning".
  *
  * Float semantics: IEEE-754 binary32, no contraction (build with
  * -ffp-contract=off), correctly rounded / and sqrt.  sin/cos of the camera

@@ -1,0 +1,222 @@
+"""CPU suite (-m "not gpu"): the oracle against the reference-kernel golden vectors, the host
+logic (SVO builders, ray table, tiling), and the C-ABI surface.  No compute call needs a GPU."""
+import glob
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import scenes
+import voxel_raycaster_amd as vrc
+from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "orc_*.npz")))
+
+
+# ---------------------------------------------------------------- C ABI surface
+def test_cabi_exports_every_declared_symbol():
+    text = open(os.path.join(ROOT, "include", "vrc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(vrc_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 35
+    for name in sorted(declared):
+        assert hasattr(vrc.lib, name), f"libvrc.so does not export {name}"
+        assert name in vrc.SIGNATURES, f"python binding lacks {name}"
+
+
+def test_no_gpu_means_loud_failure(gpu_available):
+    if gpu_available:
+        pytest.skip("a GPU is present")
+    c = vrc.CLCaster()
+    assert c.init(0) is False            # no CPU fallback
+    assert c.last_status == 3            # VRC_ERR_DEVICE
+
+
+# ---------------------------------------------------------------- a1/a2 builder
+GRIDS = [(16, 1 / 16, 1), (32, 0.3, 2), (32, 0.03, 3), (64, 0.5, 4), (128, 0.01, 5)]
+
+
+@pytest.mark.parametrize("dim,density,seed", GRIDS)
+def test_builders_agree_and_validate(dim, density, seed):
+    rng = np.random.default_rng(seed)
+    g = (rng.random(dim ** 3) < density).astype(np.int8) * 5
+    buf, root = orc.octree_generate(g, dim)                       # oracle restatement, 100000-entry buffer
+    prod = vrc.Octree.Generate(g, dim, buffer_size=100000, strict_reference=True)
+    assert root == prod.root_index
+    assert np.array_equal(buf, prod.descriptor_buffer)            # two independent implementations, bit for bit
+    assert orc.octree_validate(g, dim, buf, root) == 0            # Octree::Validate (Octree.cpp:329-352)
+    assert buf[root] & 0x7FFF == 1                                # root pointer forced to 1 (Octree.cpp:27)
+    # exact-size, non-strict layout encodes the same grid
+    fixed = vrc.Octree.Generate(g, dim, buffer_size=0, strict_reference=False)
+    assert fixed.root_index == 0
+    assert orc.octree_validate(g, dim, fixed.descriptor_buffer, fixed.root_index) == 0
+
+
+def test_far_pointers_and_page_header_are_exercised():
+    rng = np.random.default_rng(5)
+    g = (rng.random(128 ** 3) < 0.02).astype(np.int8) * 5
+    buf, root = orc.octree_generate(g, 128)
+    used = buf[root:]
+    assert (used == np.uint64(0xFFFFFFFFFFFFFFFF)).sum() >= 1     # page header every 0x8000 slots (Octree.cpp:251-262)
+    far = ((used >> np.uint64(15)) & np.uint64(1)).astype(bool) & (used != np.uint64(0xFFFFFFFFFFFFFFFF))
+    assert far.sum() >= 1                                          # far-pointer descriptors (Octree.cpp:264-286)
+    assert orc.octree_validate(g, 128, buf, root) == 0
+    prod = vrc.Octree.Generate(g, 128, buffer_size=100000, strict_reference=True)
+    assert np.array_equal(buf, prod.descriptor_buffer)
+
+
+def test_dense_overflow_is_reported_not_corrupted():
+    g = np.full(128 ** 3, 5, dtype=np.int8)                       # dense 128^3 overflows 100000 entries
+    with pytest.raises(OverflowError):
+        orc.octree_generate(g, 128)
+    with pytest.raises(vrc.VrcError):
+        vrc.Octree.Generate(g, 128, buffer_size=100000)
+    ok = vrc.Octree.Generate(g, 128, buffer_size=0, strict_reference=False)
+    assert orc.octree_validate(g, 128, ok.descriptor_buffer, ok.root_index) == 0
+
+
+def test_get_oct_vox_matches_product_getvoxel():
+    rng = np.random.default_rng(9)
+    dim = 64
+    g = (rng.random(dim ** 3) < 0.02).astype(np.int8) * 5
+    buf, root = orc.octree_generate(g, dim)
+    o = vrc.Octree(buf, root, dim)
+    for _ in range(500):
+        p = rng.integers(-3, dim + 3, size=3)
+        ts = orc.get_oct_vox(p, buf, root, dim)
+        found, res, sub = o.GetVoxel(p)
+        assert bool(ts.found) == found and ts.resolution == res and tuple(ts.sub_oct_pos) == sub
+        if all(0 <= v < dim for v in p):
+            x, y, z = p
+            assert found == bool(g[x + dim * (y + dim * z)])
+
+
+def test_all_solid_16_is_the_app_default_map():
+    m = vrc.Map(16, buffer_size=100000)                           # ArrayMap ctor fills with 5
+    assert (m.array_map == 5).all()
+    ts = orc.get_oct_vox((2, 2, 7), m.octree.descriptor_buffer, m.octree.root_index, 16)
+    assert ts.found == 1 and ts.resolution == 1 and tuple(ts.sub_oct_pos) == (2, 2, 7)
+
+
+@pytest.mark.parametrize("depth", [5, 6, 7])
+def test_sparse_terrain_builder_equals_dense_builder(depth):
+    dim = 1 << depth
+    oct_sparse, height = vrc.shell_terrain(depth, seed=1, thickness=2, strict_reference=False)
+    grid = vrc.shell_terrain_dense(depth, seed=1, thickness=2)
+    oct_dense = vrc.Octree.Generate(grid, dim, buffer_size=0, strict_reference=False)
+    assert oct_sparse.root_index == oct_dense.root_index
+    assert np.array_equal(oct_sparse.descriptor_buffer, oct_dense.descriptor_buffer)
+    assert orc.octree_validate(grid, dim, oct_sparse.descriptor_buffer, oct_sparse.root_index) == 0
+    assert height.min() >= dim // 4 and height.max() < 3 * dim // 4 + 1
+
+
+# ---------------------------------------------------------------- a4 ray table
+def test_viewport_table():
+    assert math.sin(1.57).hex() == "0x1.fffff55c67bb1p-1"         # the double constants of CLCaster.cpp:253-255
+    assert math.cos(1.57).hex() == "0x1.a181296fadbfbp-11"
+    t = orc.create_viewport(64, 48)
+    n = np.linalg.norm(t[..., :3].astype(np.float64), axis=-1)
+    assert np.abs(n - 1).max() < 1e-6 and (t[..., 3] == 0).all()
+    assert (t[:, 32, 1] == 0).all()                               # x == W/2 column: ray.y == 0
+    c = t[24, 32]
+    assert c[2] > 0.999 and abs(c[0]) < 1e-3 and c[0] < 0          # centre ray ~ (-8e-4, 0, 1): +z before pitch/yaw
+    odd = orc.create_viewport(5, 5)
+    assert (odd[4] == 0).all() and (odd[:, 4] == 0).all()         # odd sizes: last row/column never filled
+
+
+# ---------------------------------------------------------------- a5/a6 kernel restatement
+def _render(s, using_octree, atlas, w=96, h=64, **kw):
+    buf, root = orc.octree_generate(s["grid"], s["dim"])
+    md = 20 if s["dim"] <= 16 else 3 * s["dim"]
+    return orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=s["lights"], atlas=atlas,
+                       tile_dim=(16, 16), descriptors=buf, root_index=root, octree_dim=s["dim"], using_octree=using_octree,
+                       grid=s["grid"], max_distance=md, **kw)
+
+
+@pytest.mark.parametrize("make", [scenes.app_default, scenes.floor_pillars, scenes.open_sky, scenes.axis_aligned,
+                                  scenes.random_sparse])
+def test_svo_occupancy_path_equals_array_branch(make, atlas):
+    s = make()
+    a_img, a_hits, a_ctr = _render(s, 1, atlas)
+    o_img, o_hits, o_ctr = _render(s, 0, atlas)
+    assert np.array_equal(a_img.view(np.uint32), o_img.view(np.uint32))
+    assert np.array_equal(a_hits[..., :7], o_hits[..., :7])
+    for k in ("primary_rays", "shadow_rays", "n_tex", "n_steps", "unwritten"):
+        assert a_ctr[k] == o_ctr[k]
+    assert a_ctr["n_map"] > 0 and o_ctr["n_map"] == 0
+
+
+def test_unwritten_pixels_keep_initial_image(atlas):
+    s = scenes.axis_aligned()
+    img, hits, ctr = _render(s, 1, atlas, w=64, h=48)
+    assert ctr["unwritten"] == 48
+    col = img[:, 32]
+    assert np.allclose(col, [1, 1, 1, 100 / 255])                  # CLCaster.cpp:280-286
+    assert (hits[:, 32, orc_flags()] & 1 == 0).all()
+    rgba = orc.image_to_rgba8(img)
+    assert tuple(rgba[0, 32]) == (255, 255, 255, 100)
+
+
+def orc_flags():
+    return 5
+
+
+def test_mirror_bounce_and_shadow_flags(atlas):
+    s = scenes.mirror_wall()
+    img, hits, ctr = _render(s, 1, atlas)
+    assert (hits[..., 3] == 6).sum() > 0                           # primary hits on the mirror
+    assert ctr["n_tex"] >= ctr["primary_rays"]                     # mirror texel + possibly a second texel
+    s = scenes.floor_pillars()
+    img, hits, ctr = _render(s, 1, atlas)
+    flags = hits[..., 5]
+    assert ((flags & 4) != 0).sum() > 0                            # some pixels are in shadow
+    assert np.allclose(img[(flags & 4) != 0][:, 3].max(), 0.1 * 1.0, atol=0.1)
+
+
+def test_primary_only_extension(atlas):
+    s = scenes.floor_pillars()
+    img, hits, ctr = _render(s, 1, atlas, shadow_rays=0)
+    assert ctr["shadow_rays"] == 0 and ctr["primary_rays"] > 0
+
+
+def test_threads_do_not_change_the_frame(atlas):
+    s = scenes.random_sparse()
+    a = _render(s, 0, atlas, threads=1)
+    b = _render(s, 0, atlas, threads=4)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+# ---------------------------------------------------------------- a7 Ray::Cast
+def test_ray_cast_as_written_is_constant():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        o = rng.random(3) * 10
+        d = rng.standard_normal(3)
+        col, steps = orc.ray_cast(None, (0, 0, 0), o, d, as_written=True)
+        assert col == (172, 245, 251, 200) and steps == 1
+
+
+def test_ray_cast_restored_hits_floor():
+    dim = 16
+    g = np.zeros((dim, dim, dim), dtype=np.int8)
+    g[0:2] = 5
+    col, steps = orc.ray_cast(g.reshape(-1), (dim, dim, dim), (8.5, 8.5, 10.5), (0.1, 0.2, -1.0), as_written=False)
+    assert col[:3] == (255, 120, 255) and 8 <= steps <= 12
+
+
+# ---------------------------------------------------------------- committed regression vectors
+@pytest.mark.skipif(not GOLDEN, reason="tests/golden/orc_*.npz missing")
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_reproduces_committed_vectors(path):
+    """tests/golden/orc_*.npz were produced by this oracle (tests/make_golden.py), NOT by the
+    reference (which cannot run here, see oracle/vrc_oracle.h): they pin the oracle against
+    accidental change and give the GPU tests committed inputs/outputs."""
+    import golden_io
+    g = golden_io.load(path)
+    img, hits, ctr = golden_io.render_with_oracle(g)
+    assert np.array_equal(img.view(np.uint32), g["image"].view(np.uint32))
+    assert np.array_equal(hits, g["hits"])
+    assert ctr == g["counters"]

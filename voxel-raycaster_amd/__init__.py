@@ -62,6 +62,7 @@ SIGNATURES = {
     "vrc_assign_octree_attachments": (C.c_int, [_H, C.POINTER(C.c_uint32), C.c_uint64, _u64p, C.c_uint64]),
     "vrc_release_octree": (C.c_int, [_H]),
     "vrc_create_viewport": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_float, C.c_float]),
+    "vrc_create_viewport_table": (C.c_int, [_H, C.c_int32, C.c_int32, _f32p]),
     "vrc_release_viewport": (C.c_int, [_H]),
     "vrc_create_texture_atlas": (C.c_int, [_H, _u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vrc_assign_camera": (C.c_int, [_H, _f32p, _f32p]),
@@ -265,6 +266,12 @@ class CLCaster:
     def create_viewport(self, width: int, height: int, v_fov: float = 0.0, h_fov: float = 0.0) -> bool:
         self.viewport_size = (int(width), int(height))
         return self._ok(lib.vrc_create_viewport(self._h, width, height, v_fov, h_fov))
+
+    def create_viewport_table(self, table: np.ndarray) -> bool:
+        """Extension: host-supplied float4 ray table [h, w, 4]."""
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        self.viewport_size = (int(t.shape[1]), int(t.shape[0]))
+        return self._ok(lib.vrc_create_viewport_table(self._h, t.shape[1], t.shape[0], _ptr(t, _f32p)))
 
     def release_viewport(self) -> bool:
         return self._ok(lib.vrc_release_viewport(self._h))

@@ -224,11 +224,28 @@ int vrc_release_octree(vrc_caster *h) {
     return VRC_OK;
 }
 
+static int install_viewport(vrc_caster *h, int32_t width, int32_t height, std::vector<float> &table) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    release(h->d_viewport); release(h->d_image); release(h->d_hits);
+    const size_t npix = (size_t)width * height;
+    HIP_TRY(h, hipMalloc((void **)&h->d_viewport, 16 * npix));
+    HIP_TRY(h, hipMemcpy(h->d_viewport, table.data(), 16 * npix, hipMemcpyHostToDevice));
+    // image starts as RGBA8 (255,255,255,100)  (CLCaster.cpp:280-286)
+    for (size_t i = 0; i < npix; i++) {
+        table[4 * i + 0] = 1.0f; table[4 * i + 1] = 1.0f; table[4 * i + 2] = 1.0f; table[4 * i + 3] = 100.0f / 255.0f;
+    }
+    HIP_TRY(h, hipMalloc((void **)&h->d_image, 16 * npix));
+    HIP_TRY(h, hipMemcpy(h->d_image, table.data(), 16 * npix, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc((void **)&h->d_hits, 32 * npix));
+    HIP_TRY(h, hipMemset(h->d_hits, 0, 32 * npix));
+    h->width = width; h->height = height;
+    h->validated = false;
+    return VRC_OK;
+}
+
 int vrc_create_viewport(vrc_caster *h, int32_t width, int32_t height, float v_fov, float h_fov) {
     (void)v_fov; (void)h_fov;              // ignored by the reference too (CLCaster.cpp:233-275)
     if (!h || width <= 0 || height <= 0) return fail(h, VRC_ERR_INVALID_ARGUMENT, "create_viewport: bad size");
-    HIP_TRY(h, hipSetDevice(h->device));
-    release(h->d_viewport); release(h->d_image); release(h->d_hits);
     const size_t npix = (size_t)width * height;
     std::vector<float> table(4 * npix, 0.0f);
     // base ray (-800, x, y) slewed by the literal 1.57 about Y in double, then
@@ -244,19 +261,13 @@ int vrc_create_viewport(vrc_caster *h, int32_t width, int32_t height, float v_fo
             float *t = &table[4 * ((size_t)(x + width / 2) + (size_t)width * (size_t)(y + height / 2))];
             t[0] = rx / len; t[1] = ry / len; t[2] = rz / len; t[3] = 0.0f;
         }
-    HIP_TRY(h, hipMalloc((void **)&h->d_viewport, 16 * npix));
-    HIP_TRY(h, hipMemcpy(h->d_viewport, table.data(), 16 * npix, hipMemcpyHostToDevice));
-    // image starts as RGBA8 (255,255,255,100)  (CLCaster.cpp:280-286)
-    for (size_t i = 0; i < npix; i++) {
-        table[4 * i + 0] = 1.0f; table[4 * i + 1] = 1.0f; table[4 * i + 2] = 1.0f; table[4 * i + 3] = 100.0f / 255.0f;
-    }
-    HIP_TRY(h, hipMalloc((void **)&h->d_image, 16 * npix));
-    HIP_TRY(h, hipMemcpy(h->d_image, table.data(), 16 * npix, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMalloc((void **)&h->d_hits, 32 * npix));
-    HIP_TRY(h, hipMemset(h->d_hits, 0, 32 * npix));
-    h->width = width; h->height = height;
-    h->validated = false;
-    return VRC_OK;
+    return install_viewport(h, width, height, table);
+}
+
+int vrc_create_viewport_table(vrc_caster *h, int32_t width, int32_t height, const float *table) {
+    if (!h || !table || width <= 0 || height <= 0) return fail(h, VRC_ERR_INVALID_ARGUMENT, "create_viewport_table: bad argument");
+    std::vector<float> copy(table, table + (size_t)4 * width * height);
+    return install_viewport(h, width, height, copy);
 }
 
 int vrc_release_viewport(vrc_caster *h) {
