@@ -1,0 +1,277 @@
+// raycast_common.hpp -- device code shared by the two raycast kernels: the ray
+// set-up, the hit block and the epilogue of kernels/ray_caster_kernel.cl, written
+// once so the dense-array kernel and the SVO kernel cannot drift apart.
+//
+// Numerics: built with -ffp-contract=off, IEEE divide/sqrt; every float
+// expression is evaluated in the order the reference source states it, so the
+// results are bit-identical to the CPU oracle (oracle/vrc_oracle.c).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "vrc_params.h"
+
+namespace vrc {
+
+__device__ __forceinline__ float min_cl(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float max_cl(float a, float b) { return a < b ? b : a; }
+__device__ __forceinline__ float mix_cl(float x, float y, float a) { return x + (y - x) * a; }
+__device__ __forceinline__ int isign(float v) { return (v > 0.0f) - (v < 0.0f); }
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return ax * bx + ay * by + az * bz;
+}
+
+struct Vec3 { float x, y, z; };
+
+// OpenCL normalize(): v / |v|, v itself when it is all zero
+__device__ __forceinline__ Vec3 normalize3(Vec3 v) {
+    float l2 = dot3(v.x, v.y, v.z, v.x, v.y, v.z);
+    if (l2 == 0.0f) return v;
+    float l = sqrtf(l2);
+    return Vec3{v.x / l, v.y / l, v.z / l};
+}
+
+// view_light (ray_caster_kernel.cl:78-99)
+__device__ __forceinline__ void view_light(float out[4], const float in_color[4], Vec3 light,
+                                           const float light_color[4], Vec3 view, int mx, int my, int mz) {
+    if (light.x == 0.0f && light.y == 0.0f && light.z == 0.0f) {
+        out[0] = out[1] = out[2] = out[3] = 0.0f;
+        return;
+    }
+    float d = sqrtf(dot3(light.x, light.y, light.z, light.x, light.y, light.z)) * 0.01f;
+    d *= d;
+    Vec3 nmask = normalize3(Vec3{(float)mx, (float)my, (float)mz});
+    Vec3 nlight = normalize3(light);
+    float diffuse = max_cl(dot3(nmask.x, nmask.y, nmask.z, nlight.x, nlight.y, nlight.z), 0.1f);
+    float specular = 0.0f;
+    if (diffuse > 0.0f) {
+        Vec3 nview = normalize3(view);
+        Vec3 halfway = normalize3(Vec3{nlight.x + nview.x, nlight.y + nview.y, nlight.z + nview.z});
+        specular = max_cl(dot3(nmask.x, nmask.y, nmask.z, halfway.x, halfway.y, halfway.z), 0.0f);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        out[c] = in_color[c] + (diffuse * light_color[c] + specular * light_color[c] / d);
+}
+
+// Per-ray state of the reference kernel's locals (ray_caster_kernel.cl:276-337).
+struct Ray {
+    float rdx, rdy, rdz;                 // ray_dir
+    int sx, sy, sz;                      // voxel_step
+    int vx, vy, vz;                      // voxel
+    float dtx, dty, dtz;                 // delta_t
+    float itx, ity, itz;                 // intersection_t
+    int fmx, fmy, fmz;                   // face_mask
+    int distance_traveled, max_distance;
+    unsigned bounce_count;
+    float voxel_color[4], color_accumulator[4];
+    float fog_distance;
+    bool shadow_ray, written;
+    int flags;
+    int hit_vx, hit_vy, hit_vz, hit_mat, hit_face;
+    unsigned c_tex, c_shadow;
+};
+
+// :276-323 + the frame-constant bias of :342-354.  Returns false for the
+// zero-component early return (:293-294): nothing is written for that pixel.
+__device__ __forceinline__ bool ray_setup(Ray &r, const RaycastParams &p, long pix) {
+    r.hit_vx = r.hit_vy = r.hit_vz = -1;
+    r.hit_mat = r.hit_face = r.flags = 0;
+    r.distance_traveled = 0;
+    r.bounce_count = 0;
+    r.written = false;
+    r.c_tex = r.c_shadow = 0;
+
+    const float4 pm = reinterpret_cast<const float4 *>(p.viewport)[pix];
+    {
+        const float s1 = p.trig[0], c1 = p.trig[1], s2 = p.trig[2], c2 = p.trig[3];
+        float x = pm.z * s1 + pm.x * c1;                                      // pitch :280-284
+        float y = pm.y;
+        float z = pm.z * c1 - pm.x * s1;
+        r.rdx = x * c2 - y * s2;                                              // yaw :287-291
+        r.rdy = x * s2 + y * c2;
+        r.rdz = z;
+    }
+    if (r.rdx == 0.0f || r.rdy == 0.0f || r.rdz == 0.0f) return false;        // :293-294
+
+    r.sx = isign(r.rdx); r.sy = isign(r.rdy); r.sz = isign(r.rdz);            // :298
+    const float flx = floorf(p.cam_pos[0]), fly = floorf(p.cam_pos[1]), flz = floorf(p.cam_pos[2]);
+    r.vx = (int)flx; r.vy = (int)fly; r.vz = (int)flz;                        // :302
+    r.dtx = fabsf(1.0f / r.rdx); r.dty = fabsf(1.0f / r.rdy); r.dtz = fabsf(1.0f / r.rdz);   // :307
+    {
+        float ox = r.dtx * (p.cam_pos[0] - flx), oy = r.dty * (p.cam_pos[1] - fly), oz = r.dtz * (p.cam_pos[2] - flz);
+        r.itx = ox * -(float)r.sx; r.ity = oy * -(float)r.sy; r.itz = oz * -(float)r.sz;        // :317
+        r.itx += r.dtx * -1.0f * (r.itx < 0.0f ? -1.0f : 0.0f);                                  // :323
+        r.ity += r.dty * -1.0f * (r.ity < 0.0f ? -1.0f : 0.0f);
+        r.itz += r.dtz * -1.0f * (r.itz < 0.0f ? -1.0f : 0.0f);
+    }
+    r.itx += (float)p.frame[0]; r.ity += (float)p.frame[1]; r.itz += (float)p.frame[2];         // :353-354
+
+    r.max_distance = p.max_distance;                                          // :326
+    r.fmx = r.fmy = r.fmz = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { r.voxel_color[c] = 0.0f; r.color_accumulator[c] = 0.0f; }
+    r.fog_distance = 0.0f;
+    r.shadow_ray = false;
+    r.written = true;
+    return true;
+}
+
+// :563-568, entered with the voxel already stepped out of the map
+__device__ __forceinline__ void oob_exit(Ray &r) {
+    r.vx -= r.sx * r.fmx; r.vy -= r.sy * r.fmy; r.vz -= r.sz * r.fmz;
+    const float k = 1.0f - max_cl((float)r.distance_traveled / 700.0f, 0.0f);
+#pragma unroll
+    for (int c = 0; c < 4; c++) r.color_accumulator[c] = mix_cl(0.0f, r.voxel_color[c], k);
+    r.color_accumulator[3] *= 4.0f;
+    r.flags |= kFlagOob;
+}
+
+// :575-711 for voxel_data in {5, 6}.  Returns true when the loop breaks / the
+// kernel returns, false when the (redirected) ray keeps stepping.
+__device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastParams &p) {
+    float fpx = 0.f, fpy = 0.f, fpz = 0.f, tfx = 0.f, tfy = 0.f;
+    float sgx = 1.0f, sgy = 1.0f, sgz = 1.0f;
+    if (r.fmx == 1) {                                                         // :586-599
+        sgx = (float)((double)sgx * -1.0);
+        float z_percent = (r.itz - (r.itx - r.dtx)) / r.dtz;
+        float y_percent = (r.ity - (r.itx - r.dtx)) / r.dty;
+        fpx = 1.00001f; fpy = y_percent; fpz = z_percent;
+        tfx = fpy; tfy = fpz;
+    } else if (r.fmy == 1) {                                                  // :601-608
+        sgy = (float)((double)sgy * -1.0);
+        float x_percent = (r.itx - (r.ity - r.dty)) / r.dtx;
+        float z_percent = (r.itz - (r.ity - r.dty)) / r.dtz;
+        fpx = x_percent; fpy = 1.00001f; fpz = z_percent;
+        tfx = fpx; tfy = fpz;
+    } else if (r.fmz == 1) {                                                  // :610-618
+        sgz = (float)((double)sgz * -1.0);
+        float x_percent = (r.itx - (r.itz - r.dtz)) / r.dtx;
+        float y_percent = (r.ity - (r.itz - r.dtz)) / r.dty;
+        fpx = x_percent; fpy = y_percent; fpz = 1.00001f;
+        tfx = fpx; tfy = fpy;
+    }
+    // :626-643 quadrant flips
+    if (r.rdx > 0.0f) fpx = -fpx + 1.0f;
+    if (r.rdx < 0.0f) tfx = -tfx + 1.0f;
+    if (r.rdy > 0.0f) {
+        fpy = -fpy + 1.0f;
+    } else {
+        tfx = (float)(1.0 - (double)tfx);
+        if (r.fmz == 1) { tfx = 1.0f - tfx; tfy = 1.0f - tfy; }
+    }
+    if (r.rdz > 0.0f) fpz = -fpz + 1.0f;
+    if (r.rdz < 0.0f) tfy = -tfy + 1.0f;
+
+    if (r.hit_mat == 0 && !r.shadow_ray) {
+        r.hit_vx = r.vx; r.hit_vy = r.vy; r.hit_vz = r.vz; r.hit_mat = voxel_data;
+        r.hit_face = r.fmx | (r.fmy << 1) | (r.fmz << 2);
+    }
+
+    if (r.shadow_ray) {                                                       // :707-710
+        r.color_accumulator[3] = 0.1f;
+        r.flags |= kFlagShadowHit;
+        return true;
+    }
+
+    const bool mirror = (voxel_data == 6);
+    // :652-656 / :684-688  tile (5,0) halved, tile (3,4) quartered
+    int tx = (int)(tfx * (float)p.tiles_x) + (int)((mirror ? 3.0f : 5.0f) * (float)p.tiles_x);
+    int ty = (int)(tfy * (float)p.tiles_y) + (int)((mirror ? 4.0f : 0.0f) * (float)p.tiles_y);
+    tx = tx < 0 ? 0 : (tx >= p.atlas_w ? p.atlas_w - 1 : tx);                 // undefined in OpenCL: clamp
+    ty = ty < 0 ? 0 : (ty >= p.atlas_h ? p.atlas_h - 1 : ty);
+    const uchar4 t8 = reinterpret_cast<const uchar4 *>(p.atlas)[(long)tx + (long)p.atlas_w * ty];
+    r.c_tex++;
+    const float div = mirror ? 4.0f : 2.0f;
+    r.voxel_color[0] += ((float)t8.x / 255.0f) / div;
+    r.voxel_color[1] += ((float)t8.y / 255.0f) / div;
+    r.voxel_color[2] += ((float)t8.z / 255.0f) / div;
+
+    const Vec3 light_pos{p.light_pos[0], p.light_pos[1], p.light_pos[2]};
+    const Vec3 hit_pos{(float)r.vx + fpx, (float)r.vy + fpy, (float)r.vz + fpz};
+    if (!mirror) {                                                            // :649-679
+        r.shadow_ray = true;
+        view_light(r.color_accumulator, r.voxel_color,
+                   Vec3{hit_pos.x - light_pos.x, hit_pos.y - light_pos.y, hit_pos.z - light_pos.z}, p.light_rgbi,
+                   Vec3{hit_pos.x - p.cam_pos[0], hit_pos.y - p.cam_pos[1], hit_pos.z - p.cam_pos[2]},
+                   r.fmx * r.sx, r.fmy * r.sy, r.fmz * r.sz);
+        r.fog_distance = (float)r.distance_traveled;                          // :666
+        if (!p.shadow_rays) return true;                                      // extension: primary rays only
+        {
+            const float ddx = (float)r.vx - light_pos.x, ddy = (float)r.vy - light_pos.y, ddz = (float)r.vz - light_pos.z;
+            r.max_distance = (int)((float)r.distance_traveled + sqrtf(dot3(ddx, ddy, ddz, ddx, ddy, ddz)));   // :667
+        }
+        const Vec3 nd = normalize3(Vec3{light_pos.x - hit_pos.x, light_pos.y - hit_pos.y, light_pos.z - hit_pos.z});
+        r.rdx = nd.x; r.rdy = nd.y; r.rdz = nd.z;                             // :670
+        if (r.rdx == 0.0f || r.rdy == 0.0f || r.rdz == 0.0f) { r.written = false; return true; }   // :671-672
+        r.c_shadow = 1;
+        r.flags |= kFlagShadowCast;
+        r.vx -= r.sx * r.fmx; r.vy -= r.sy * r.fmy; r.vz -= r.sz * r.fmz;     // :674
+        r.sx = isign(r.rdx); r.sy = isign(r.rdy); r.sz = isign(r.rdz);        // :675
+    } else {                                                                  // :682-704
+        r.rdx *= sgx; r.rdy *= sgy; r.rdz *= sgz;                             // :693
+        if (r.rdx == 0.0f || r.rdy == 0.0f || r.rdz == 0.0f) { r.written = false; return true; }
+        r.vx -= r.sx * r.fmx; r.vy -= r.sy * r.fmy; r.vz -= r.sz * r.fmz;     // :697
+        // :698 precedence quirk: +1 for both signs
+        r.sx = (-1 * (r.rdx > 0.0f ? -1 : 0)) - (r.rdx < 0.0f ? -1 : 0);
+        r.sy = (-1 * (r.rdy > 0.0f ? -1 : 0)) - (r.rdy < 0.0f ? -1 : 0);
+        r.sz = (-1 * (r.rdz > 0.0f ? -1 : 0)) - (r.rdz < 0.0f ? -1 : 0);
+        r.bounce_count += 1;
+    }
+    r.dtx = fabsf(1.0f / r.rdx); r.dty = fabsf(1.0f / r.rdy); r.dtz = fabsf(1.0f / r.rdz);   // :677 / :700
+    r.itx = r.dtx * (hit_pos.x - floorf(hit_pos.x)) * (float)r.sx;                            // :678 / :701
+    r.ity = r.dty * (hit_pos.y - floorf(hit_pos.y)) * (float)r.sy;
+    r.itz = r.dtz * (hit_pos.z - floorf(hit_pos.z)) * (float)r.sz;
+    r.itx += r.dtx * -(r.itx < 0.0f ? -1.0f : 0.0f);                                          // :679 / :702
+    r.ity += r.dty * -(r.ity < 0.0f ? -1.0f : 0.0f);
+    r.itz += r.dtz * -(r.itz < 0.0f ? -1.0f : 0.0f);
+    return false;
+}
+
+// :716-721 + the hit record
+__device__ __forceinline__ void ray_finish(Ray &r, const RaycastParams &p, long pix, unsigned c_desc) {
+    if (r.written) {
+        const float k = 1.0f - max_cl(r.fog_distance / 700.0f, 0.0f);         // :716
+        reinterpret_cast<float4 *>(p.image)[pix] =
+            make_float4(mix_cl(0.0f, r.color_accumulator[0], k), mix_cl(0.0f, r.color_accumulator[1], k),
+                        mix_cl(0.0f, r.color_accumulator[2], k), mix_cl(0.0f, r.color_accumulator[3], k));
+        r.flags |= kFlagWritten;
+    }
+    int4 *hp = reinterpret_cast<int4 *>(p.hits) + 2 * pix;
+    hp[0] = make_int4(r.hit_vx, r.hit_vy, r.hit_vz, r.hit_mat);
+    hp[1] = make_int4(r.hit_face, r.flags | ((int)(r.bounce_count & 3) << 4), r.distance_traveled, (int)c_desc);
+}
+
+// block id -> pixel (XCD-aware: block b runs on XCD b % 8, so give each XCD a
+// contiguous part of the image and keep its private L2 warm with one region
+// of the octree)
+__device__ __forceinline__ void block_pixel(const RaycastParams &p, int &px, int &py) {
+    const int nblocks = gridDim.x;
+    int bid = blockIdx.x;
+    const int per_xcd = nblocks >> 3;
+    if (per_xcd > 0 && bid < (per_xcd << 3)) bid = (bid & 7) * per_xcd + (bid >> 3);
+    const int local_ty = bid / p.blocks_x;                // tile row among this rank's rows
+    const int bx = bid - local_ty * p.blocks_x;
+    const int band = local_ty / p.band_tiles;
+    const int tile_y = (band * p.tile_world + p.tile_rank) * p.band_tiles + (local_ty - band * p.band_tiles);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    px = (bx * kTilesPerBlock + wave) * kTileW + (lane & 7);
+    py = tile_y * kTileH + (lane >> 3);
+}
+
+// per-block counter partials (no global atomics): wave shuffle reduce, LDS, one row per block
+__device__ __forceinline__ void publish_counters(const RaycastParams &p, unsigned long long *block_ctr,
+                                                 const unsigned (&vals)[7]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        unsigned long long v = vals[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && v) atomicAdd(&block_ctr[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < kCtrCount) p.counters[(long)blockIdx.x * kCtrCount + threadIdx.x] = block_ctr[threadIdx.x];
+}
+
+}  // namespace vrc

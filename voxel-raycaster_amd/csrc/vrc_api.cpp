@@ -392,6 +392,9 @@ int vrc_compute_async(vrc_caster *h) {
     for (int a = 0; a < 3; a++) p.light_pos[a] = h->lights[4 + a];
     p.max_distance = (int32_t)setting_or(h, "max_distance", 20);
     p.shadow_rays = (int32_t)setting_or(h, "shadow_rays", 1);
+    p.event_threshold = (int32_t)setting_or(h, "event_threshold", 24);   // tuning knob, no effect on results
+    if (p.event_threshold < 1) p.event_threshold = 1;
+    if (p.event_threshold > 64) p.event_threshold = 64;
     p.frame = h->d_frame;
 
     const int tile_rows = (h->height + vrc::kTileH - 1) / vrc::kTileH;

@@ -52,6 +52,7 @@ struct RaycastParams {
     int32_t *frame;
     int32_t max_distance;
     int32_t shadow_rays;
+    int32_t event_threshold;          // SVO kernel: parked lanes per wave before node events are serviced
     // row tiling (multi-GPU)
     int32_t tile_rank, tile_world, band_tiles;   // band_tiles = band_rows / kTileH
     int32_t blocks_x;                 // ceil(width / 32)
