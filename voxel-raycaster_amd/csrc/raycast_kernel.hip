@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
 // ---------------------------------------------------------------------------
 // SVO branch
 // ---------------------------------------------------------------------------
-enum LaneMode { kStep = 0, kEvent = 1, kDone = 2 };
+enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3 };
 
 __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const RaycastParams p) {
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
     int mode = kDone;
 
     // stepping state while inside a known-empty node: countdown of steps to the
-    // node face per axis (float: exact for counts < 2^24), voxel_a = base_a - s_a * n_a
-    float nx = 1.0f, ny = 1.0f, nz = 1.0f;
+    // node face per axis, voxel_a = base_a - s_a * n_a
+    float nx = 1.0f, ny = 1.0f, nz = 1.0f;               // exact: counts < 2^24
     float fxf = 0.0f, fyf = 0.0f, fzf = 0.0f;             // face_mask of the last step, as 0.0 / 1.0
     int bx = 0, by = 0, bz = 0;
 
@@ -178,49 +178,75 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
     }
 
     const int threshold = p.event_threshold;
+    const int shade_threshold = p.shade_threshold;
     for (;;) {
+        // ---- stepping burst: lanes run :357-560 inside their known-empty node until they leave
+        // it (or hit the step cap); the burst ends once `threshold` lanes have parked
         if (mode == kStep) {
-            // one iteration of :357-560 inside a known-empty node
-            const float m = fminf(fminf(r.itx, r.ity), r.itz);
-            fxf = r.itx <= m ? 1.0f : 0.0f;               // :558 (ties step several axes)
-            fyf = r.ity <= m ? 1.0f : 0.0f;
-            fzf = r.itz <= m ? 1.0f : 0.0f;
-            r.itx = __builtin_fmaf(r.dtx, fxf, r.itx);    // :559, exact: dt * {0,1} has no rounding
-            r.ity = __builtin_fmaf(r.dty, fyf, r.ity);
-            r.itz = __builtin_fmaf(r.dtz, fzf, r.itz);
-            nx -= fxf; ny -= fyf; nz -= fzf;              // :560 as countdowns
-            if (fminf(fminf(nx, ny), nz) == 0.0f) {
-                mode = kEvent;                            // left the node: bounds test + lookup pending
+            const int started = __popcll(__ballot(true));
+            const int it_limit = r.max_distance - r.distance_traveled;       // >= 1 iterations left (:357)
+            int it;                                        // iterations this lane executed in the burst
+            asm volatile("v_mov_b32 %0, 0" : "=v"(it));   // per-lane VGPR counter (a uniform one costs 2 copies per step)
+            const int last = it_limit - 1;
+            bool go;
+            do {
+                // the burst goes on while fewer than `threshold` of its lanes have parked (exec = survivors)
+                const bool more = __popcll(__ballot(true)) + threshold > started;
+                const float m = fminf(fminf(r.itx, r.ity), r.itz);
+                fxf = r.itx <= m ? 1.0f : 0.0f;           // :558 (ties step several axes)
+                fyf = r.ity <= m ? 1.0f : 0.0f;
+                fzf = r.itz <= m ? 1.0f : 0.0f;
+                r.itx = __builtin_fmaf(r.dtx, fxf, r.itx);   // :559, exact: dt * {0,1} has no rounding
+                r.ity = __builtin_fmaf(r.dty, fyf, r.ity);
+                r.itz = __builtin_fmaf(r.dtz, fzf, r.itz);
+                nx -= fxf; ny -= fyf; nz -= fzf;          // :560 as countdowns to the node face
+                go = (fminf(fminf(nx, ny), nz) != 0.0f) & (it != last) & more;
+                ++it;
+            } while (go);
+            if (fminf(fminf(nx, ny), nz) == 0.0f) {       // left the node: bounds test + lookup pending
+                mode = kEvent;
+                r.distance_traveled += it - 1;            // the leaving iteration's :714 comes after the lookup
             } else {
-                r.distance_traveled++;                    // :714
-                if (r.distance_traveled >= r.max_distance) mode = kDone;   // :357
+                r.distance_traveled += it;                // :714
+                if (it == it_limit) mode = kDone;         // :357
             }
         }
-        const unsigned long long ev = __ballot(mode == kEvent);
+        unsigned long long ev = __ballot(mode == kEvent);
         const unsigned long long st = __ballot(mode == kStep);
-        if ((ev | st) == 0ULL) break;
-        if (st != 0ULL && __popcll(ev) < threshold) continue;
+        unsigned long long sh = __ballot(mode == kShade);
+        if ((ev | st | sh) == 0ULL) break;
 
-        if (mode == kEvent) {
-            r.vx = bx - r.sx * (int)nx; r.vy = by - r.sy * (int)ny; r.vz = bz - r.sz * (int)nz;
-            r.fmx = (int)fxf; r.fmy = (int)fyf; r.fmz = (int)fzf;
-            if (r.vx >= p.map_dim[0] || r.vy >= p.map_dim[1] || r.vz >= p.map_dim[2] || r.vx < 0 || r.vy < 0 || r.vz < 0) {
-                oob_exit(r);                              // :563-568
-                broke = 1;
-                mode = kDone;
-            } else {
-                const int b = locate(r.vx, r.vy, r.vz);
-                bool stop = false;
-                if (b >= 0) {
-                    enter_node(b);
-                } else {                                  // occupied: material 5 (no attachments yet)
-                    stop = hit_block(r, 5, p);            // :575-711
-                    if (!stop) enter_single();
-                }
-                if (stop) {
+        // ---- node events
+        if (ev != 0ULL) {
+            if (mode == kEvent) {
+                r.vx = bx - r.sx * (int)nx; r.vy = by - r.sy * (int)ny; r.vz = bz - r.sz * (int)nz;
+                r.fmx = (int)fxf; r.fmy = (int)fyf; r.fmz = (int)fzf;
+                if (r.vx >= p.map_dim[0] || r.vy >= p.map_dim[1] || r.vz >= p.map_dim[2] || r.vx < 0 || r.vy < 0 || r.vz < 0) {
+                    oob_exit(r);                          // :563-568
                     broke = 1;
                     mode = kDone;
                 } else {
+                    const int b = locate(r.vx, r.vy, r.vz);
+                    if (b >= 0) {
+                        enter_node(b);
+                        r.distance_traveled++;            // :714
+                        mode = (r.distance_traveled < r.max_distance) ? kStep : kDone;   // :357
+                    } else {
+                        mode = kShade;                    // occupied voxel: the hit block is deferred
+                    }
+                }
+            }
+            sh = __ballot(mode == kShade);
+        }
+
+        // ---- hit block (:575-711): expensive and needed ~twice per pixel
+        if (sh != 0ULL && (__ballot(mode == kStep) == 0ULL || __popcll(sh) >= shade_threshold)) {
+            if (mode == kShade) {
+                if (hit_block(r, 5, p)) {                 // material 5: no attachments yet
+                    broke = 1;
+                    mode = kDone;
+                } else {
+                    enter_single();
                     r.distance_traveled++;                // :714
                     mode = (r.distance_traveled < r.max_distance && r.bounce_count < 2) ? kStep : kDone;   // :357
                 }
@@ -292,7 +318,7 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
     if (nblocks <= 0) return hipSuccess;
     if (p.svo) {
         const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
-        const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t);
+        const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t) + (size_t)p.lds_pad_bytes;
         hipLaunchKernelGGL(raycast_svo_kernel, dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
     } else {
         hipLaunchKernelGGL(raycast_array_kernel, dim3(nblocks), dim3(kBlockThreads), 0, stream, p);

@@ -6,6 +6,7 @@
 // HIP streams/events on one MI355X instead of an OpenCL queue + GL interop.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -392,9 +393,10 @@ int vrc_compute_async(vrc_caster *h) {
     for (int a = 0; a < 3; a++) p.light_pos[a] = h->lights[4 + a];
     p.max_distance = (int32_t)setting_or(h, "max_distance", 20);
     p.shadow_rays = (int32_t)setting_or(h, "shadow_rays", 1);
-    p.event_threshold = (int32_t)setting_or(h, "event_threshold", 24);   // tuning knob, no effect on results
-    if (p.event_threshold < 1) p.event_threshold = 1;
-    if (p.event_threshold > 64) p.event_threshold = 64;
+    // wave scheduling knobs of the SVO kernel; they never change results
+    p.event_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "event_threshold", 6)));
+    p.shade_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "shade_threshold", 64)));
+    p.lds_pad_bytes = (int32_t)std::min<int64_t>(120 * 1024, std::max<int64_t>(0, setting_or(h, "lds_pad_bytes", 0)));
     p.frame = h->d_frame;
 
     const int tile_rows = (h->height + vrc::kTileH - 1) / vrc::kTileH;

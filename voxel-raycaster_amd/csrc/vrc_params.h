@@ -53,6 +53,8 @@ struct RaycastParams {
     int32_t max_distance;
     int32_t shadow_rays;
     int32_t event_threshold;          // SVO kernel: parked lanes per wave before node events are serviced
+    int32_t shade_threshold;          // ... and before the hit block runs
+    int32_t lds_pad_bytes;            // experiment knob: extra dynamic LDS to lower occupancy
     // row tiling (multi-GPU)
     int32_t tile_rank, tile_world, band_tiles;   // band_tiles = band_rows / kTileH
     int32_t blocks_x;                 // ceil(width / 32)
