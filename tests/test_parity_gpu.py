@@ -153,6 +153,34 @@ def test_row_tiling_union_equals_full_frame(atlas):
         assert np.array_equal(tiling.merge_tiles(hits, h, world, band), ref_hits)
 
 
+def test_cpp_host_mirror(tmp_path, atlas):
+    """csrc/app_init_example.cpp replays Application::init_clcaster (src/Application.cpp:27-88) through the C++
+    CLCaster mirror (csrc/clcaster.hpp): its frames must equal the oracle's for the application's default scene."""
+    import subprocess
+    exe = os.path.join(ROOT, "voxel-raycaster_amd", "app_init_example")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    w, h = 96, 64
+    atlas_path = tmp_path / "atlas.rgba"
+    atlas.tofile(atlas_path)
+    out = subprocess.run([exe, str(w), str(h), str(atlas_path), str(tmp_path / "frame")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    s = scenes.app_default()
+    m = vrc.Map(16, buffer_size=100000)
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[0] = s["lights"][0]
+    for suffix, cam_pos in ((".image.f32", (2.34, 2.5, 7.17)), (".image2.f32", (2.34, 2.5, np.float32(7.17) + np.float32(0.5)))):
+        img = np.fromfile(str(tmp_path / "frame") + suffix, dtype=np.float32).reshape(h, w, 4)
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=(2.424, 3.141), cam_pos=cam_pos, lights=li, atlas=atlas,
+                                     tile_dim=(16, 16), descriptors=m.octree.descriptor_buffer,
+                                     root_index=m.octree.root_index, octree_dim=16, using_octree=0, max_distance=20)
+        assert np.array_equal(img.view(np.uint32), oimg.view(np.uint32))
+    hits = np.fromfile(str(tmp_path / "frame") + ".hits.i32", dtype=np.int32).reshape(h, w, 8)
+    oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=(2.424, 3.141), cam_pos=(2.34, 2.5, 7.17), lights=li, atlas=atlas,
+                                 tile_dim=(16, 16), descriptors=m.octree.descriptor_buffer, root_index=m.octree.root_index,
+                                 octree_dim=16, using_octree=0, max_distance=20)
+    assert np.array_equal(hits, ohits)
+
+
 def _bench_scene(depth):
     import bench
     return bench.build_scene(depth)

@@ -249,9 +249,18 @@ __device__ __forceinline__ void block_pixel(const RaycastParams &p, int &px, int
     const int nblocks = gridDim.x;
     int bid = blockIdx.x;
     const int per_xcd = nblocks >> 3;
-    if (per_xcd > 0 && bid < (per_xcd << 3)) bid = (bid & 7) * per_xcd + (bid >> 3);
-    const int local_ty = bid / p.blocks_x;                // tile row among this rank's rows
-    const int bx = bid - local_ty * p.blocks_x;
+    int local_ty, bx;
+    if (p.xcd_mode == 1 && per_xcd > 0 && bid < (per_xcd << 3) && (p.local_tile_rows & 7) == 0) {
+        // XCD k renders the tile rows k, k+8, k+16, ...: equal sky/ground mix per XCD
+        const int j = bid >> 3;
+        local_ty = (j / p.blocks_x) * 8 + (bid & 7);
+        bx = j % p.blocks_x;
+    } else {
+        // XCD k renders the k-th contiguous eighth of the image (mode 0); mode 2: no remap
+        if (p.xcd_mode == 0 && per_xcd > 0 && bid < (per_xcd << 3)) bid = (bid & 7) * per_xcd + (bid >> 3);
+        local_ty = bid / p.blocks_x;                      // tile row among this rank's rows
+        bx = bid - local_ty * p.blocks_x;
+    }
     const int band = local_ty / p.band_tiles;
     const int tile_y = (band * p.tile_world + p.tile_rank) * p.band_tiles + (local_ty - band * p.band_tiles);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

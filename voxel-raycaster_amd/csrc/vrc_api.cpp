@@ -396,6 +396,7 @@ int vrc_compute_async(vrc_caster *h) {
     // wave scheduling knobs of the SVO kernel; they never change results
     p.event_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "event_threshold", 6)));
     p.shade_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "shade_threshold", 64)));
+    p.xcd_mode = (int32_t)setting_or(h, "xcd_mode", 1);
     p.lds_pad_bytes = (int32_t)std::min<int64_t>(120 * 1024, std::max<int64_t>(0, setting_or(h, "lds_pad_bytes", 0)));
     p.frame = h->d_frame;
 

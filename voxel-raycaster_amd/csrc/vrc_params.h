@@ -55,6 +55,7 @@ struct RaycastParams {
     int32_t event_threshold;          // SVO kernel: parked lanes per wave before node events are serviced
     int32_t shade_threshold;          // ... and before the hit block runs
     int32_t lds_pad_bytes;            // experiment knob: extra dynamic LDS to lower occupancy
+    int32_t xcd_mode;                 // block->tile map: 0 contiguous eighth per XCD, 1 tile rows interleaved over XCDs, 2 none
     // row tiling (multi-GPU)
     int32_t tile_rank, tile_world, band_tiles;   // band_tiles = band_rows / kTileH
     int32_t blocks_x;                 // ceil(width / 32)
