@@ -147,8 +147,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pmc-traffic", type=str, default=None,
-                    help="JSON file with measured HBM bytes per launch (profiles/, see DESIGN.md)")
+    ap.add_argument("--pmc-traffic", type=str, default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+                    help="JSON file with the rocprofv3 PMC measurement of HBM bytes per launch (see DESIGN.md 7)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -210,8 +210,8 @@ def main():
         bytes_per_launch = algorithmic_bytes(ctr, local_pixels, written)
         avg_kernel_s = kernel_ms / max(n_launch, 1) / 1e3
         achieved = bytes_per_launch / avg_kernel_s / 1e9
-        traffic = None
-        if args.pmc_traffic and os.path.exists(args.pmc_traffic):
+        traffic = None        # HBM bytes per launch from the committed PMC passes (N=1 headline workload only)
+        if world == 1 and args.depth == 12 and (W, H) == (1920, 1080) and args.pmc_traffic and os.path.exists(args.pmc_traffic):
             traffic = json.load(open(args.pmc_traffic)).get("hbm_bytes_per_launch")
         out = {
             "metric": "Mrays/s (primary+shadow), 1920x1080 into depth-12 SVO",
@@ -227,7 +227,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel": "raycast_kernel<SVO>",
+                         "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel": "raycast_svo_kernel",
+                         "note": "exact-parity stepping is VALU-issue bound (DESIGN.md 4): 8.4 G DDA steps vs 74 M descriptor reads per frame",
                          "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"]},
         }
         if world == 1 and not args.no_cpu_baseline:

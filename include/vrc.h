@@ -172,6 +172,11 @@ typedef struct vrc_counters {
 } vrc_counters;
 int vrc_get_counters(vrc_caster *h, vrc_counters *out);
 
+/* Wave-scheduler statistics of the SVO kernel for the most recent frame (per wave, not per lane):
+ * [0] step-loop iterations, [1] bursts, [2] node-event passes, [3] lanes serviced in them,
+ * [4] hit-block passes, [5] lanes shaded in them, [6..7] reserved.                */
+int vrc_get_scheduler_stats(vrc_caster *h, uint64_t out[8]);
+
 /* hipEvent timing of the raycast kernel on the handle's stream, accumulated
  * since the last reset (replaces GraphTimer "Compute", Application.cpp:151-155). */
 int vrc_timing_reset(vrc_caster *h);

@@ -22,7 +22,8 @@ def main():
         n, ms = c.timing()
         ctr = c.counters()
         rays = ctr["primary_rays"] + ctr["shadow_rays"]
-        print(json.dumps({name: v, "kernel_ms": round(ms / n, 3), "Mrays/s": round(rays / (ms / n) / 1e3, 1)}), flush=True)
+        print(json.dumps({name: v, "kernel_ms": round(ms / n, 3), "Mrays/s": round(rays / (ms / n) / 1e3, 1),
+                          "steps": ctr["steps"], "sched": c.scheduler_stats()}), flush=True)
 
 if __name__ == "__main__":
     main()

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vrc_read_hits": (C.c_int, [_H, _i32p, C.c_size_t]),
     "vrc_device_image": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "vrc_get_counters": (C.c_int, [_H, C.POINTER(Counters)]),
+    "vrc_get_scheduler_stats": (C.c_int, [_H, _u64p]),
     "vrc_timing_reset": (C.c_int, [_H]),
     "vrc_timing_get": (C.c_int, [_H, _u64p, C.POINTER(C.c_double)]),
     "vrc_octree_generate": (C.c_int, [_i8p, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(_u64p), _u64p, _u64p]),
@@ -337,6 +338,13 @@ class CLCaster:
         if not self._ok(lib.vrc_get_counters(self._h, C.byref(c))):
             raise VrcError(self.last_error())
         return c.as_dict()
+
+    def scheduler_stats(self) -> dict:
+        out = (C.c_uint64 * 8)()
+        if not self._ok(lib.vrc_get_scheduler_stats(self._h, out)):
+            raise VrcError(self.last_error())
+        names = ("wave_step_iterations", "bursts", "event_passes", "event_lanes", "shade_passes", "shade_lanes")
+        return {n: int(out[i]) for i, n in enumerate(names)}
 
     def timing_reset(self) -> bool:
         return self._ok(lib.vrc_timing_reset(self._h))

@@ -179,6 +179,15 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
 
     const int threshold = p.event_threshold;
     const int shade_threshold = p.shade_threshold;
+#ifdef VRC_SCHED_STATS
+    // profiling build only (libvrc_stats.so): per-wave scheduler statistics; each event is counted by the
+    // first active lane, so the sum over lanes is the wave-level count
+    unsigned w_iters = 0, w_bursts = 0, w_ev_passes = 0, w_ev_lanes = 0, w_sh_passes = 0, w_sh_lanes = 0;
+    const int lane_id = tid & 63;
+#define VRC_STAT(var, inc) do { if (lane_id == __ffsll((long long)__ballot(true)) - 1) var += (inc); } while (0)
+#else
+#define VRC_STAT(var, inc) do { } while (0)
+#endif
     for (;;) {
         // ---- stepping burst: lanes run :357-560 inside their known-empty node until they leave
         // it (or hit the step cap); the burst ends once `threshold` lanes have parked
@@ -202,7 +211,9 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
                 nx -= fxf; ny -= fyf; nz -= fzf;          // :560 as countdowns to the node face
                 go = (fminf(fminf(nx, ny), nz) != 0.0f) & (it != last) & more;
                 ++it;
+                VRC_STAT(w_iters, 1);
             } while (go);
+            VRC_STAT(w_bursts, 1);
             if (fminf(fminf(nx, ny), nz) == 0.0f) {       // left the node: bounds test + lookup pending
                 mode = kEvent;
                 r.distance_traveled += it - 1;            // the leaving iteration's :714 comes after the lookup
@@ -218,6 +229,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
 
         // ---- node events
         if (ev != 0ULL) {
+            VRC_STAT(w_ev_passes, 1); VRC_STAT(w_ev_lanes, __popcll(ev));
             if (mode == kEvent) {
                 r.vx = bx - r.sx * (int)nx; r.vy = by - r.sy * (int)ny; r.vz = bz - r.sz * (int)nz;
                 r.fmx = (int)fxf; r.fmy = (int)fyf; r.fmz = (int)fzf;
@@ -241,6 +253,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
 
         // ---- hit block (:575-711): expensive and needed ~twice per pixel
         if (sh != 0ULL && (__ballot(mode == kStep) == 0ULL || __popcll(sh) >= shade_threshold)) {
+            VRC_STAT(w_sh_passes, 1); VRC_STAT(w_sh_lanes, __popcll(sh));
             if (mode == kShade) {
                 if (hit_block(r, 5, p)) {                 // material 5: no attachments yet
                     broke = 1;
@@ -263,6 +276,14 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
         }
         ray_finish(r, p, pix, c_desc);
     }
+#ifdef VRC_SCHED_STATS
+    if (w_iters) atomicAdd(&block_ctr[kCtrWaveIters], (unsigned long long)w_iters);
+    if (w_bursts) atomicAdd(&block_ctr[kCtrBursts], (unsigned long long)w_bursts);
+    if (w_ev_passes) atomicAdd(&block_ctr[kCtrEventPasses], (unsigned long long)w_ev_passes);
+    if (w_ev_lanes) atomicAdd(&block_ctr[kCtrEventLanes], (unsigned long long)w_ev_lanes);
+    if (w_sh_passes) atomicAdd(&block_ctr[kCtrShadePasses], (unsigned long long)w_sh_passes);
+    if (w_sh_lanes) atomicAdd(&block_ctr[kCtrShadeLanes], (unsigned long long)w_sh_lanes);
+#endif
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
     publish_counters(p, block_ctr, vals);
 }

@@ -51,6 +51,7 @@ struct vrc_caster {
     int32_t tile_rank = 0, tile_world = 1, band_rows = 8;
     bool validated = false;
     int last_blocks = 0;
+    uint64_t sched_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // kernel timing
     struct EvPair { hipEvent_t a, b; };
@@ -508,6 +509,16 @@ int vrc_get_counters(vrc_caster *h, vrc_counters *out) {
     out->descriptor_reads = c[vrc::kCtrDesc]; out->texel_reads = c[vrc::kCtrTex];
     out->map_reads = c[vrc::kCtrMap]; out->steps = c[vrc::kCtrSteps];
     out->unwritten_pixels = c[vrc::kCtrUnwritten];
+    for (int i = 0; i < 8; i++) h->sched_stats[i] = c[8 + i];
+    return VRC_OK;
+}
+
+int vrc_get_scheduler_stats(vrc_caster *h, uint64_t out[8]) {
+    if (!h || !out) return VRC_ERR_INVALID_ARGUMENT;
+    vrc_counters tmp;
+    int rc = vrc_get_counters(h, &tmp);
+    if (rc != VRC_OK) return rc;
+    for (int i = 0; i < 8; i++) out[i] = h->sched_stats[i];
     return VRC_OK;
 }
 

@@ -19,7 +19,9 @@ constexpr int kFlagWritten = 1, kFlagShadowCast = 2, kFlagShadowHit = 4, kFlagOo
 
 // counters[] slots (device, uint64)
 enum CounterSlot {
-    kCtrPrimary = 0, kCtrShadow, kCtrDesc, kCtrTex, kCtrMap, kCtrSteps, kCtrUnwritten, kCtrCount = 8
+    kCtrPrimary = 0, kCtrShadow, kCtrDesc, kCtrTex, kCtrMap, kCtrSteps, kCtrUnwritten,
+    // wave-scheduler statistics of the SVO kernel (one count per wave, not per lane)
+    kCtrWaveIters = 8, kCtrBursts, kCtrEventPasses, kCtrEventLanes, kCtrShadePasses, kCtrShadeLanes, kCtrCount = 16
 };
 
 struct RaycastParams {
