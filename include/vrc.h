@@ -72,6 +72,12 @@ int vrc_release_map(vrc_caster *h);
  * uploads but never reads (ray_caster_kernel.cl:143-144) are optional.        */
 int vrc_assign_octree(vrc_caster *h, const uint64_t *descriptors, uint64_t n_descriptors,
                       uint64_t root_index);
+/* Attachment layout (ours; the reference never defined one): lookup[i] (parallel to
+ * the descriptor array) = slot in `attachments` of bottom-level descriptor i, whose
+ * byte k is the int8 material of child k.  With attachments assigned the SVO branch
+ * renders exactly what the array branch renders for the same grid (materials 5 and 6
+ * are solid to the renderer, everything else is passed through,
+ * ray_caster_kernel.cl:575); without them every valid voxel is material 5.        */
 int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_t n_lookup,
                                   const uint64_t *attachments, uint64_t n_attachments);
 /* CLCaster::release_octree (CLCaster.cpp:119-131) */
@@ -194,6 +200,18 @@ int vrc_timing_get(vrc_caster *h, uint64_t *n_launches, double *total_kernel_ms)
 int vrc_octree_generate(const int8_t *grid, uint32_t dim, uint64_t buffer_size,
                         int strict_reference, uint64_t **descriptors,
                         uint64_t *n_descriptors, uint64_t *root_index);
+
+/* Material attachments (layout: see vrc_assign_octree_attachments) for an array built from `grid`.
+ * Results are malloc'ed; release with vrc_free.                                  */
+int vrc_octree_attachments_from_grid(const int8_t *grid, uint32_t dim, const uint64_t *descriptors,
+                                     uint64_t n_descriptors, uint64_t root_index, uint32_t **lookup,
+                                     uint64_t **attachments, uint64_t *n_attachments);
+/* ... and for the procedural scene: material 6 (mirror) where hash(x,y,z,seed) % mirror_period == 0,
+ * else 5; mirror_period 0 = all 5.                                               */
+int vrc_scene_shell_terrain_attachments(uint32_t depth, uint64_t seed, uint32_t mirror_period,
+                                        const uint64_t *descriptors, uint64_t n_descriptors,
+                                        uint64_t root_index, uint32_t **lookup, uint64_t **attachments,
+                                        uint64_t *n_attachments);
 
 /* Procedural sparse builder for grids too large to materialise (SURVEY 8d
  * "shell-terrain"): solid iff h(x,y)-thickness <= z <= h(x,y).  Emits the same

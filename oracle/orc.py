@@ -49,6 +49,7 @@ class Scene(C.Structure):
         ("lights", _f32p), ("light_count", C.c_int32),
         ("atlas_rgba8", _u8p), ("atlas_dim", C.c_int32 * 2), ("tile_dim", C.c_int32 * 2),
         ("descriptors", _u64p), ("n_descriptors", C.c_uint64),
+        ("attachment_lookup", C.POINTER(C.c_uint32)), ("attachments", _u64p),
         ("octree_dimensions", C.c_int64), ("using_octree", C.c_int64), ("octree_root_index", C.c_int64),
         ("max_distance", C.c_int32), ("shadow_rays", C.c_int32), ("cam_trig", C.c_float * 4)]
 
@@ -125,7 +126,7 @@ def camera_trig(cam_dir) -> np.ndarray:
 
 def raycast(*, width, height, cam_dir, cam_pos, lights, atlas, tile_dim, descriptors, root_index, octree_dim,
             using_octree, grid=None, map_dim=None, max_distance=20, shadow_rays=1, viewport=None, trig=None,
-            rows=None, threads=1, want_hits=True):
+            rows=None, threads=1, want_hits=True, attachment_lookup=None, attachments=None):
     """Render with the oracle.  Returns (image[h,w,4] f32, hits[h,w,8] i32 or None, counters dict)."""
     keep = []
     s = Scene()
@@ -155,6 +156,12 @@ def raycast(*, width, height, cam_dir, cam_pos, lights, atlas, tile_dim, descrip
     keep.append(de)
     s.descriptors = _p(de, _u64p)
     s.n_descriptors = de.size
+    if attachment_lookup is not None and attachments is not None:
+        al = np.ascontiguousarray(attachment_lookup, dtype=np.uint32)
+        ab = np.ascontiguousarray(attachments, dtype=np.uint64)
+        keep += [al, ab]
+        s.attachment_lookup = _p(al, C.POINTER(C.c_uint32))
+        s.attachments = _p(ab, _u64p)
     s.octree_dimensions = octree_dim
     s.using_octree = using_octree
     s.octree_root_index = root_index

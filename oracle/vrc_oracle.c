@@ -464,6 +464,13 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
         }
         if (svo) {
             voxel_data = svo_locate(&cur, voxel) ? 5 : 0;
+            /* extension: material from the attachment buffers the reference
+             * allocates but never reads; only bottom-level descriptors carry materials */
+            if (voxel_data && s->attachment_lookup && s->attachments && cur.top == cur.n - 1) {
+                const uint64_t a = s->attachments[s->attachment_lookup[cur.idx[cur.top]]];
+                const int k = (voxel[0] & 1) | ((voxel[1] & 1) << 1) | ((voxel[2] & 1) << 2);
+                voxel_data = (int8_t)(a >> (8 * k));
+            }
         } else {
             /* :569 -- note dim.z is the y-stride */
             voxel_data = s->map[(int64_t)voxel[0] + (int64_t)s->map_dim[0] * ((int64_t)voxel[1] + (int64_t)s->map_dim[2] * voxel[2])];

@@ -105,6 +105,8 @@ typedef struct {
     int32_t         tile_dim[2];      /* 11 */
     const uint64_t *descriptors;      /* 12 */
     uint64_t        n_descriptors;
+    const uint32_t *attachment_lookup;   /* 13 optional: per-descriptor slot into attachments (layout: include/vrc.h) */
+    const uint64_t *attachments;         /* 14 optional: 8 int8 materials per bottom-level descriptor; NULL => material 5 */
     /* settings buffer (CLCaster.cpp:1029-1109, Application.cpp:35-39) */
     int64_t         octree_dimensions;   /* OCTDIM */
     int64_t         using_octree;        /* OCTENABLED: 0 => SVO occupancy, !=0 => dense array */

@@ -149,6 +149,39 @@ def test_svo_occupancy_path_equals_array_branch(make, atlas):
     assert a_ctr["n_map"] > 0 and o_ctr["n_map"] == 0
 
 
+def _with_pass_through(s):
+    """Add voxels of a material the renderer ignores (only 5 and 6 are solid, ray_caster_kernel.cl:575)."""
+    dim = s["dim"]
+    g = np.array(s["grid"], dtype=np.int8).reshape(dim, dim, dim).copy()
+    g[dim // 2:dim // 2 + 2, dim // 3:dim // 3 + 3, 2:dim - 2][g[dim // 2:dim // 2 + 2, dim // 3:dim // 3 + 3, 2:dim - 2] == 0] = 1
+    out = dict(s)
+    out["grid"] = g.reshape(-1)
+    return out
+
+
+@pytest.mark.parametrize("make", [scenes.mirror_wall, scenes.floor_pillars, scenes.random_sparse])
+def test_svo_with_attachments_equals_array_branch_for_any_materials(make, atlas):
+    """with per-voxel materials in the attachment buffers the SVO branch renders exactly what
+    the array branch renders -- mirrors (6) bounce, other materials are passed through."""
+    s = _with_pass_through(make())
+    dim = s["dim"]
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000).attach_materials_from_grid(s["grid"])
+    kw = dict(width=96, height=64, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=s["lights"], atlas=atlas,
+              tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index, octree_dim=dim, grid=s["grid"],
+              max_distance=3 * dim)
+    a_img, a_hits, a_ctr = orc.raycast(using_octree=1, **kw)
+    o_img, o_hits, o_ctr = orc.raycast(using_octree=0, attachment_lookup=o.attachment_lookup, attachments=o.attachment_buffer, **kw)
+    assert np.array_equal(a_img.view(np.uint32), o_img.view(np.uint32))
+    assert np.array_equal(a_hits[..., :7], o_hits[..., :7])
+    for k in ("primary_rays", "shadow_rays", "n_tex", "n_steps", "unwritten"):
+        assert a_ctr[k] == o_ctr[k]
+    # attachment layout: one slot per bottom-level descriptor, slot 0 = sentinel of 5s
+    assert o.attachment_buffer[0] == 0x0505050505050505
+    bottom = ((o.descriptor_buffer >> np.uint64(24)) & np.uint64(0xFF)) == np.uint64(0xFF)
+    bottom &= o.descriptor_buffer != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert int((o.attachment_lookup != 0).sum()) == o.attachment_buffer.size - 1 <= int(bottom.sum())
+
+
 def test_unwritten_pixels_keep_initial_image(atlas):
     s = scenes.axis_aligned()
     img, hits, ctr = _render(s, 1, atlas, w=64, h=48)

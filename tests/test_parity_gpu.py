@@ -87,6 +87,30 @@ def test_hip_reproduces_committed_vectors(path):
     assert np.array_equal(c.read_image().view(np.uint32), g["image"].view(np.uint32))
 
 
+@pytest.mark.parametrize("make", [scenes.mirror_wall, scenes.floor_pillars, scenes.random_sparse],
+                         ids=["mirror_wall", "floor_pillars", "random_sparse"])
+def test_svo_with_attachments_equals_array_and_oracle(make, atlas):
+    """Per-voxel materials through the attachment buffers: the SVO kernel must equal the oracle
+    bit for bit and render what the array kernel renders (mirrors bounce, other materials pass through)."""
+    from test_oracle_cpu import _with_pass_through
+    s = _with_pass_through(make())
+    dim, w, h = s["dim"], 160, 120
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000).attach_materials_from_grid(s["grid"])
+    md = 3 * dim
+    svo = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+    arr = make_caster(o, dim, 1, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md, grid=s["grid"])
+    assert svo.compute() and arr.compute()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=svo._li,
+                                    atlas=atlas, tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                    octree_dim=dim, using_octree=0, max_distance=md, attachment_lookup=o.attachment_lookup,
+                                    attachments=o.attachment_buffer)
+    assert_same(svo.read_image(), svo.read_hits(), svo.counters(), oimg, ohits, octr)
+    assert np.array_equal(svo.read_image().view(np.uint32), arr.read_image().view(np.uint32))
+    assert np.array_equal(svo.read_hits()[..., :7], arr.read_hits()[..., :7])
+    if make is scenes.mirror_wall:
+        assert (ohits[..., 3] == 6).sum() > 0
+
+
 def test_primary_only_and_live_camera(atlas):
     s = scenes.floor_pillars()
     dim = s["dim"]

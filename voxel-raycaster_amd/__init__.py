@@ -86,6 +86,10 @@ SIGNATURES = {
     "vrc_timing_get": (C.c_int, [_H, _u64p, C.POINTER(C.c_double)]),
     "vrc_octree_generate": (C.c_int, [_i8p, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(_u64p), _u64p, _u64p]),
     "vrc_scene_shell_terrain": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, C.c_int, C.POINTER(_u64p), _u64p, _u64p, _i32p]),
+    "vrc_octree_attachments_from_grid": (C.c_int, [_i8p, C.c_uint32, _u64p, C.c_uint64, C.c_uint64,
+                                                    C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(_u64p), _u64p]),
+    "vrc_scene_shell_terrain_attachments": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint32, _u64p, C.c_uint64, C.c_uint64,
+                                                       C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(_u64p), _u64p]),
     "vrc_scene_shell_terrain_dense": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, _i8p]),
     "vrc_scene_atlas": (C.c_int, [C.c_int32, C.c_int32, _u8p]),
     "vrc_octree_get_voxel": (C.c_int, [_u64p, C.c_uint64, C.c_uint32, _i32p, _i32p, _i32p, _i32p]),
@@ -116,6 +120,8 @@ class Octree:
         self.descriptor_buffer = np.ascontiguousarray(descriptors, dtype=np.uint64)
         self.root_index = int(root_index)
         self.dim = int(dim)
+        self.attachment_lookup = None      # uint32[n_descriptors]  (Octree.h:46)
+        self.attachment_buffer = None      # uint64[]               (Octree.h:49)
 
     @classmethod
     def Generate(cls, data: np.ndarray, dim: int, buffer_size: int = 0, strict_reference: bool = True) -> "Octree":
@@ -133,6 +139,32 @@ class Octree:
         arr = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
         lib.vrc_free(out)
         return cls(arr, root.value, dim)
+
+    def _take_attachments(self, lookup_p, attach_p, n_attach):
+        self.attachment_lookup = np.ctypeslib.as_array(lookup_p, shape=(self.descriptor_buffer.size,)).copy()
+        self.attachment_buffer = np.ctypeslib.as_array(attach_p, shape=(n_attach,)).copy()
+        lib.vrc_free(lookup_p)
+        lib.vrc_free(attach_p)
+
+    def attach_materials_from_grid(self, data: np.ndarray) -> "Octree":
+        """Fill attachment_lookup / attachment_buffer (Octree.h:46-50) with the per-voxel materials of `data`."""
+        data = np.ascontiguousarray(data, dtype=np.int8).reshape(-1)
+        lp, ap, n = C.POINTER(C.c_uint32)(), _u64p(), C.c_uint64()
+        rc = lib.vrc_octree_attachments_from_grid(_ptr(data, _i8p), self.dim, _ptr(self.descriptor_buffer, _u64p),
+                                                  self.descriptor_buffer.size, self.root_index, C.byref(lp), C.byref(ap), C.byref(n))
+        if rc != 0:
+            raise VrcError(f"vrc_octree_attachments_from_grid: {STATUS.get(rc, rc)}")
+        self._take_attachments(lp, ap, n.value)
+        return self
+
+    def attach_materials_procedural(self, depth: int, seed: int = 1, mirror_period: int = 64) -> "Octree":
+        lp, ap, n = C.POINTER(C.c_uint32)(), _u64p(), C.c_uint64()
+        rc = lib.vrc_scene_shell_terrain_attachments(depth, seed, mirror_period, _ptr(self.descriptor_buffer, _u64p),
+                                                     self.descriptor_buffer.size, self.root_index, C.byref(lp), C.byref(ap), C.byref(n))
+        if rc != 0:
+            raise VrcError(f"vrc_scene_shell_terrain_attachments: {STATUS.get(rc, rc)}")
+        self._take_attachments(lp, ap, n.value)
+        return self
 
     def GetVoxel(self, position):
         """Octree::GetVoxel (src/map/Octree.cpp:45-158): (found, resolution, sub_oct_pos)."""
@@ -240,7 +272,13 @@ class CLCaster:
     def assign_octree(self, map_: "Map | Octree") -> bool:
         oct_ = map_.octree if isinstance(map_, Map) else map_
         buf = oct_.descriptor_buffer
-        return self._ok(lib.vrc_assign_octree(self._h, _ptr(buf, _u64p), buf.size, oct_.root_index))
+        if not self._ok(lib.vrc_assign_octree(self._h, _ptr(buf, _u64p), buf.size, oct_.root_index)):
+            return False
+        if oct_.attachment_lookup is not None and oct_.attachment_buffer is not None:
+            return self._ok(lib.vrc_assign_octree_attachments(
+                self._h, _ptr(oct_.attachment_lookup, C.POINTER(C.c_uint32)), oct_.attachment_lookup.size,
+                _ptr(oct_.attachment_buffer, _u64p), oct_.attachment_buffer.size))
+        return True
 
     def release_octree(self) -> bool:
         return self._ok(lib.vrc_release_octree(self._h))

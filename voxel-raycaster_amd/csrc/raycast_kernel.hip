@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
 
     Ray r;
     unsigned c_primary = 0, c_desc = 0, c_unwritten = 0, broke = 0;
-    int mode = kDone;
+    int mode = kDone, mat = 5;
 
     // stepping state while inside a known-empty node: countdown of steps to the
     // node face per axis, voxel_a = base_a - s_a * n_a
@@ -144,6 +144,18 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
             lds_stack[top * kBlockThreads + tid] = cur;   // level top+1 lives in slot top
             top++;
         }
+    };
+    // material of the solid voxel the cursor just found (attachments: see include/vrc.h); 5 without them
+    auto solid_material = [&](int x, int y, int z) -> int {
+        if (!p.attach_lookup || top != n - 1) return 5;   // only bottom-level descriptors carry materials
+        uint64_t node = p.root_index;
+        if (top > 0) {
+            const uint64_t parent = (top == 1) ? root_entry : lds_stack[(top - 2) * kBlockThreads + tid];
+            const int slot = ((x >> 1) & 1) | (((y >> 1) & 1) << 1) | (((z >> 1) & 1) << 2);
+            node = (parent >> 16) + (uint64_t)(__popc((unsigned)parent & 0xffu & ((2u << slot) - 1u)) - 1);
+        }
+        const uint64_t a = p.attachments[p.attach_lookup[node]];
+        return (int)(int8_t)(a >> (8 * ((x & 1) | ((y & 1) << 1) | ((z & 1) << 2))));
     };
     // park the ray in the empty node of size 2^b around its voxel
     auto enter_node = [&](int b) {
@@ -244,7 +256,14 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
                         r.distance_traveled++;            // :714
                         mode = (r.distance_traveled < r.max_distance) ? kStep : kDone;   // :357
                     } else {
-                        mode = kShade;                    // occupied voxel: the hit block is deferred
+                        mat = solid_material(r.vx, r.vy, r.vz);
+                        if (mat == 5 || mat == 6) {       // :575
+                            mode = kShade;                // the hit block is deferred
+                        } else {                          // any other material is passed through
+                            enter_single();
+                            r.distance_traveled++;        // :714
+                            mode = (r.distance_traveled < r.max_distance) ? kStep : kDone;   // :357
+                        }
                     }
                 }
             }
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
         if (sh != 0ULL && (__ballot(mode == kStep) == 0ULL || __popcll(sh) >= shade_threshold)) {
             VRC_STAT(w_sh_passes, 1); VRC_STAT(w_sh_lanes, __popcll(sh));
             if (mode == kShade) {
-                if (hit_block(r, 5, p)) {                 // material 5: no attachments yet
+                if (hit_block(r, mat, p)) {
                     broke = 1;
                     mode = kDone;
                 } else {

@@ -261,6 +261,54 @@ struct ShellSource {
 
 bool is_pow2(uint32_t v) { return v >= 2 && (v & (v - 1)) == 0; }
 
+// Per-voxel materials for the SVO path ("attachments").  The reference allocates
+// octree_attachment_lookup_buffer / octree_attachment_buffer (src/CLCaster.cpp:108-110) but never
+// defines or reads them (ray_caster_kernel.cl:143-144); the layout is ours:
+//   lookup[i]   uint32, parallel to the descriptor array: for a bottom-level descriptor i (node = 2^3
+//               voxels) the slot in `attachments` holding its materials, 0 otherwise
+//   attachments uint64: byte k = material (int8) of child slot k = x | y<<1 | z<<2; slot 0 is a
+//               sentinel of eight 5s
+template <class MaterialFn>
+void walk_materials(const uint64_t *desc, uint64_t index, int x, int y, int z, int size, const MaterialFn &mat,
+                    std::vector<uint32_t> &lookup, std::vector<uint64_t> &attach) {
+    const uint64_t d = desc[index];
+    const unsigned valid = (unsigned)(d >> 16) & 0xff, leaf = (unsigned)(d >> 24) & 0xff;
+    if (size == 2) {
+        uint64_t packed = 0;
+        for (int k = 0; k < 8; k++)
+            packed |= (uint64_t)(uint8_t)mat(x + (k & 1), y + ((k >> 1) & 1), z + ((k >> 2) & 1)) << (8 * k);
+        lookup[index] = (uint32_t)attach.size();
+        attach.push_back(packed);
+        return;
+    }
+    const uint64_t base = (d & kFarBit) ? desc[index + (d & 0x7fff)] : index + (d & 0x7fff);
+    const int h = size / 2;
+    int before = 0;
+    for (int k = 0; k < 8; k++) {
+        if (!(valid & (1u << k))) continue;
+        if (!(leaf & (1u << k)))
+            walk_materials(desc, base + (uint64_t)before, x + ((k & 1) ? h : 0), y + ((k & 2) ? h : 0), z + ((k & 4) ? h : 0), h,
+                           mat, lookup, attach);
+        before++;
+    }
+}
+
+template <class MaterialFn>
+int build_attachments(const uint64_t *desc, uint64_t n, uint64_t root, uint32_t dim, const MaterialFn &mat,
+                      uint32_t **lookup_out, uint64_t **attach_out, uint64_t *n_attach) {
+    std::vector<uint32_t> lookup((size_t)n, 0u);
+    std::vector<uint64_t> attach;
+    attach.push_back(0x0505050505050505ULL);
+    walk_materials(desc, root, 0, 0, 0, (int)dim, mat, lookup, attach);
+    *lookup_out = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
+    *attach_out = (uint64_t *)malloc(sizeof(uint64_t) * attach.size());
+    if (!*lookup_out || !*attach_out) { free(*lookup_out); free(*attach_out); return VRC_ERR_OUT_OF_MEMORY; }
+    memcpy(*lookup_out, lookup.data(), sizeof(uint32_t) * (size_t)n);
+    memcpy(*attach_out, attach.data(), sizeof(uint64_t) * attach.size());
+    *n_attach = attach.size();
+    return VRC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -302,6 +350,29 @@ int vrc_scene_shell_terrain_dense(uint32_t depth, uint64_t seed, int32_t thickne
         for (int64_t y = 0; y < dim; y++)
             for (int64_t x = 0; x < dim; x++) grid[x + dim * (y + dim * z)] = src.solid(x, y, z) ? 5 : 0;
     return VRC_OK;
+}
+
+int vrc_octree_attachments_from_grid(const int8_t *grid, uint32_t dim, const uint64_t *descriptors, uint64_t n_descriptors,
+                                     uint64_t root_index, uint32_t **lookup, uint64_t **attachments, uint64_t *n_attachments) {
+    if (!grid || !descriptors || !lookup || !attachments || !n_attachments || !is_pow2(dim) || root_index >= n_descriptors)
+        return VRC_ERR_INVALID_ARGUMENT;
+    const int64_t d = dim;
+    auto mat = [grid, d](int x, int y, int z) { return grid[x + d * (y + d * z)]; };
+    return build_attachments(descriptors, n_descriptors, root_index, dim, mat, lookup, attachments, n_attachments);
+}
+
+int vrc_scene_shell_terrain_attachments(uint32_t depth, uint64_t seed, uint32_t mirror_period, const uint64_t *descriptors,
+                                        uint64_t n_descriptors, uint64_t root_index, uint32_t **lookup,
+                                        uint64_t **attachments, uint64_t *n_attachments) {
+    if (depth < 3 || depth > 13 || !descriptors || !lookup || !attachments || !n_attachments || root_index >= n_descriptors)
+        return VRC_ERR_INVALID_ARGUMENT;
+    // material 6 (mirror) where hash(x,y,z,seed) % mirror_period == 0, else 5; 0 = no mirrors
+    auto mat = [seed, mirror_period](int x, int y, int z) -> int8_t {
+        if (!mirror_period) return 5;
+        const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)(uint32_t)x << 42) ^ ((uint64_t)(uint32_t)y << 21) ^ (uint64_t)(uint32_t)z));
+        return (h % mirror_period) == 0 ? 6 : 5;
+    };
+    return build_attachments(descriptors, n_descriptors, root_index, 1u << depth, mat, lookup, attachments, n_attachments);
 }
 
 int vrc_scene_atlas(int32_t width, int32_t height, uint8_t *rgba8) {

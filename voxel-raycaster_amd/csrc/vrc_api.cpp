@@ -207,6 +207,8 @@ int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     release(h->d_attach_lookup); release(h->d_attach);
+    if (lookup && n_lookup && n_lookup != h->n_desc)
+        return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_attachments: lookup must have one entry per descriptor (assign the octree first)");
     if (lookup && n_lookup) {
         HIP_TRY(h, hipMalloc((void **)&h->d_attach_lookup, n_lookup * sizeof(uint32_t)));
         HIP_TRY(h, hipMemcpy(h->d_attach_lookup, lookup, n_lookup * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -385,6 +387,8 @@ int vrc_compute_async(vrc_caster *h) {
     p.atlas = h->d_atlas; p.atlas_w = h->atlas_w; p.atlas_h = h->atlas_h;
     p.tiles_x = h->atlas_w / h->tile_w; p.tiles_y = h->atlas_h / h->tile_h;
     p.descriptors = h->d_desc;
+    p.attach_lookup = (h->d_attach_lookup && h->d_attach) ? h->d_attach_lookup : nullptr;
+    p.attachments = p.attach_lookup ? h->d_attach : nullptr;
     p.root_index = (uint64_t)setting_or(h, "octree_root_index", 0);
     // live buffers are re-read every frame (CL_MEM_USE_HOST_PTR semantics)
     for (int a = 0; a < 3; a++) p.cam_pos[a] = h->cam_pos[a];

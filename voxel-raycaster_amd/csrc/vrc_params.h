@@ -40,6 +40,8 @@ struct RaycastParams {
     int32_t tiles_x, tiles_y;         // atlas_dim / tile_dim (integer division)
     // arg 12 + settings: SVO
     const uint64_t *descriptors;
+    const uint32_t *attach_lookup;    // arg 13 (optional): per-descriptor slot into attachments
+    const uint64_t *attachments;      // arg 14 (optional): 8 int8 materials per bottom-level descriptor
     uint64_t root_index;
     int32_t log2_dim;                 // OCTDIM = 1 << log2_dim
     int32_t svo;                      // using_octree == 0
