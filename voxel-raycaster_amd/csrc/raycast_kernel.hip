@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
 // ---------------------------------------------------------------------------
 enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3 };
 
-__global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const RaycastParams p) {
+__global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const RaycastParams p) {
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
     __shared__ unsigned long long block_ctr[kCtrCount];
     const int tid = threadIdx.x;
@@ -206,9 +206,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
         if (mode == kStep) {
             const int started = __popcll(__ballot(true));
             const int it_limit = r.max_distance - r.distance_traveled;       // >= 1 iterations left (:357)
-            int it;                                        // iterations this lane executed in the burst
-            asm volatile("v_mov_b32 %0, 0" : "=v"(it));   // per-lane VGPR counter (a uniform one costs 2 copies per step)
-            const int last = it_limit - 1;
+            float left = (float)it_limit;                  // per-lane countdown of the step cap (exact: < 2^24)
             bool go;
             do {
                 // the burst goes on while fewer than `threshold` of its lanes have parked (exec = survivors)
@@ -221,10 +219,11 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_svo_kernel(const Raycas
                 r.ity = __builtin_fmaf(r.dty, fyf, r.ity);
                 r.itz = __builtin_fmaf(r.dtz, fzf, r.itz);
                 nx -= fxf; ny -= fyf; nz -= fzf;          // :560 as countdowns to the node face
-                go = (fminf(fminf(nx, ny), nz) != 0.0f) & (it != last) & more;
-                ++it;
+                left -= 1.0f;
+                go = (fminf(fminf(fminf(nx, ny), nz), left) != 0.0f) & more;
                 VRC_STAT(w_iters, 1);
             } while (go);
+            const int it = it_limit - (int)left;          // iterations this lane executed in the burst
             VRC_STAT(w_bursts, 1);
             if (fminf(fminf(nx, ny), nz) == 0.0f) {       // left the node: bounds test + lookup pending
                 mode = kEvent;
