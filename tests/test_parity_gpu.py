@@ -111,6 +111,38 @@ def test_svo_with_attachments_equals_array_and_oracle(make, atlas):
         assert (ohits[..., 3] == 6).sum() > 0
 
 
+@pytest.mark.parametrize("make", [scenes.floor_pillars, scenes.open_sky, scenes.random_sparse, scenes.mirror_wall],
+                         ids=["floor_pillars", "open_sky", "random_sparse", "mirror_wall"])
+def test_exact_jump_kernel_equals_oracle(make, atlas):
+    """Opt-in closed-form jumps (csrc/exact_jump.hpp, setting jump_min_run): same bits as the stepping kernel."""
+    s = make()
+    dim, w, h = s["dim"], 160, 120
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000).attach_materials_from_grid(s["grid"])
+    md = 3 * dim
+    c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+    assert c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 2)
+    assert c.compute()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=c._li,
+                                    atlas=atlas, tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                    octree_dim=dim, using_octree=0, max_distance=md, attachment_lookup=o.attachment_lookup,
+                                    attachments=o.attachment_buffer)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+
+
+def test_exact_jump_kernel_headline_frame():
+    """The jump kernel on the full depth-12 1080p frame must reproduce the stepping kernel bit for bit."""
+    sc = _bench_scene(12)
+    w, h, dim = 1920, 1080, sc["dim"]
+    c = make_caster(sc["octree"], dim, 0, sc["cam_dir"], sc["cam_pos"], sc["lights"], sc["atlas"], w, h, 3 * dim)
+    assert c.compute()
+    img, hits, ctr = c.read_image(), c.read_hits(), c.counters()
+    assert c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 8)
+    assert c.compute()
+    assert np.array_equal(c.read_hits(), hits)
+    assert np.array_equal(c.read_image().view(np.uint32), img.view(np.uint32))
+    assert c.counters() == ctr
+
+
 def test_primary_only_and_live_camera(atlas):
     s = scenes.floor_pillars()
     dim = s["dim"]

@@ -6,7 +6,7 @@ import numpy as np
 import bench
 
 def main():
-    name = sys.argv[1] if len(sys.argv) > 1 else "event_threshold"
+    name = sys.argv[1] if len(sys.argv) > 1 else "burst_steps"
     values = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8, 16, 24, 32, 48, 64]
     depth = int(os.environ.get("DEPTH", "12"))
     sc = bench.build_scene(depth)
@@ -23,7 +23,7 @@ def main():
         ctr = c.counters()
         rays = ctr["primary_rays"] + ctr["shadow_rays"]
         print(json.dumps({name: v, "kernel_ms": round(ms / n, 3), "Mrays/s": round(rays / (ms / n) / 1e3, 1),
-                          "steps": ctr["steps"], "sched": c.scheduler_stats()}), flush=True)
+                          "steps": ctr["steps"], "jump_covered": ctr["map_reads"], "sched": c.scheduler_stats()}), flush=True)
 
 if __name__ == "__main__":
     main()

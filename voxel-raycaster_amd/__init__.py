@@ -381,7 +381,7 @@ class CLCaster:
         out = (C.c_uint64 * 8)()
         if not self._ok(lib.vrc_get_scheduler_stats(self._h, out)):
             raise VrcError(self.last_error())
-        names = ("wave_step_iterations", "bursts", "event_passes", "event_lanes", "shade_passes", "shade_lanes")
+        names = ("wave_step_iterations", "bursts", "event_passes", "event_lanes", "shade_passes", "shade_lanes", "jump_attempts", "jump_successes")
         return {n: int(out[i]) for i, n in enumerate(names)}
 
     def timing_reset(self) -> bool:

@@ -15,20 +15,24 @@
 //     but while a ray is inside a node the octree says is empty, a step touches
 //     no memory and no voxel coordinates: per axis a countdown of steps to the
 //     node face replaces voxel += step, the bounds test and the lookup
-//     (17 VALU ops per step).  v_fma(dt, mask, t) with mask in {0,1} is exact,
+//     (17 VALU ops per step, -fno-slp-vectorize: v_pk_*_f32 is slow on gfx950).  v_fma(dt, mask, t) with mask in {0,1} is exact,
 //     so it equals the reference's unfused multiply-add bit for bit.
 //   * Leaving a node is an EVENT: reconstruct the voxel, pop the per-ray stack
 //     (LDS, [level][thread], conflict-free) to the common ancestor, descend.
-//     Events are rare per lane (~1 per 100 steps) but frequent per wave, so
-//     lanes that hit an event park, and the wave services events only when
-//     __ballot says enough lanes are parked (or nobody can step): the divergent
-//     step loop re-converges on wave votes instead of paying the event path
-//     on every iteration.
+//     The wave works in ROUNDS: every stepping lane runs up to burst_steps
+//     iterations (one basic block, no exec juggling), then all parked lanes are
+//     serviced together; the ~600-instruction hit block is deferred until
+//     nothing cheaper is left, so it runs a few times per wave with most lanes
+//     active.  __ballot votes pick the phases.
+//   * Opt-in (setting jump_min_run): exact_jump.hpp replaces a whole empty
+//     stretch by closed forms that reproduce the float recurrence and the
+//     iteration count bit for bit.
 //   * One wavefront = one 8x8 pixel tile (coherent rays walk the same nodes and
-//     L1/L2 lines), 4 tiles per 256-thread block, block ids remapped so each
-//     XCD renders a contiguous image region against its own L2.
+//     L1/L2 lines), 4 tiles per 256-thread block; XCD k (block id mod 8) renders
+//     the tile rows k, k+8, ...: every XCD gets the same sky/ground mix.
 #include <hip/hip_runtime.h>
 
+#include "exact_jump.hpp"
 #include "raycast_common.hpp"
 
 namespace vrc {
@@ -94,6 +98,8 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
 // ---------------------------------------------------------------------------
 enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3 };
 
+// kJump: also use the closed-form multi-iteration jumps of exact_jump.hpp (opt-in, setting jump_min_run)
+template <bool kJump>
 __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const RaycastParams p) {
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
     __shared__ unsigned long long block_ctr[kCtrCount];
@@ -189,28 +195,64 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
         }
     }
 
-    const int threshold = p.event_threshold;
     const int shade_threshold = p.shade_threshold;
+    const float jump_min_run = (float)p.jump_min_run;
+    const int burst_cap = p.burst_steps;                 // ordinary steps per round and lane
+    JumpCache jcache;
+    jump_cache_reset(jcache);
 #ifdef VRC_SCHED_STATS
     // profiling build only (libvrc_stats.so): per-wave scheduler statistics; each event is counted by the
     // first active lane, so the sum over lanes is the wave-level count
-    unsigned w_iters = 0, w_bursts = 0, w_ev_passes = 0, w_ev_lanes = 0, w_sh_passes = 0, w_sh_lanes = 0;
+    unsigned w_iters = 0, w_bursts = 0, w_ev_passes = 0, w_ev_lanes = 0, w_sh_passes = 0, w_sh_lanes = 0, w_jumps = 0;
     const int lane_id = tid & 63;
+    unsigned l_try = 0, l_ok = 0, l_cov = 0;            // lane-level: jump attempts, successes, iterations covered
 #define VRC_STAT(var, inc) do { if (lane_id == __ffsll((long long)__ballot(true)) - 1) var += (inc); } while (0)
 #else
 #define VRC_STAT(var, inc) do { } while (0)
 #endif
     for (;;) {
-        // ---- stepping burst: lanes run :357-560 inside their known-empty node until they leave
-        // it (or hit the step cap); the burst ends once `threshold` lanes have parked
+        // One round = every live lane advances to its next node event: a closed-form jump (long empty
+        // stretch) or a burst of ordinary steps (short stretch / not yet in the closed-form regime), then all
+        // parked lanes are serviced together, so each phase runs with as many lanes as possible.
+
+        // ---- phase 1: exact multi-iteration jumps (exact_jump.hpp)
+        if (kJump && mode == kStep && fminf(fminf(nx, ny), nz) >= jump_min_run) {
+#pragma nounroll
+            for (int attempt = 0; attempt < 2 && mode == kStep; attempt++) {
+                int inx = (int)nx, iny = (int)ny, inz = (int)nz;
+                const JumpResult jr = try_jump(r.itx, r.ity, r.itz, r.dtx, r.dty, r.dtz, inx, iny, inz,
+                                               r.max_distance - r.distance_traveled, jcache);
+#ifdef VRC_SCHED_STATS
+                l_try++; if (jr.iterations > 0) { l_ok++; l_cov += jr.iterations; }
+#endif
+                if (jr.iterations == 0) break;            // not in the closed-form regime: ordinary steps below
+                VRC_STAT(w_jumps, 1);
+                if (jr.capped) {                          // :357 the step cap ends the loop inside the stretch
+                    r.distance_traveled = r.max_distance;
+                    mode = kDone;
+                } else {
+                    nx = (float)inx; ny = (float)iny; nz = (float)inz;
+                    if (jr.left_node) {
+                        fxf = (float)jr.fx; fyf = (float)jr.fy; fzf = (float)jr.fz;
+                        r.distance_traveled += jr.iterations - 1;     // the leaving iteration's :714 follows the lookup
+                        mode = kEvent;
+                    } else {                              // stopped at a binade boundary: try once more
+                        r.distance_traveled += jr.iterations;
+                        if (r.distance_traveled >= r.max_distance) mode = kDone;
+                    }
+                }
+            }
+        }
+
+        // ---- phase 2: ordinary steps (:357-560) for lanes still inside their node.  A lane that is waiting
+        // to jump only takes two steps (enough to settle its progressions); the others run to their node face.
         if (mode == kStep) {
-            const int started = __popcll(__ballot(true));
-            const int it_limit = r.max_distance - r.distance_traveled;       // >= 1 iterations left (:357)
-            float left = (float)it_limit;                  // per-lane countdown of the step cap (exact: < 2^24)
+            const int true_limit = r.max_distance - r.distance_traveled;     // >= 1 iterations left (:357)
+            const int cap = (kJump && fminf(fminf(nx, ny), nz) >= jump_min_run) ? 2 : burst_cap;
+            const int it_limit = true_limit < cap ? true_limit : cap;
+            float left = (float)it_limit;                  // per-lane countdown (exact: < 2^24)
             bool go;
             do {
-                // the burst goes on while fewer than `threshold` of its lanes have parked (exec = survivors)
-                const bool more = __popcll(__ballot(true)) + threshold > started;
                 const float m = fminf(fminf(r.itx, r.ity), r.itz);
                 fxf = r.itx <= m ? 1.0f : 0.0f;           // :558 (ties step several axes)
                 fyf = r.ity <= m ? 1.0f : 0.0f;
@@ -220,7 +262,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                 r.itz = __builtin_fmaf(r.dtz, fzf, r.itz);
                 nx -= fxf; ny -= fyf; nz -= fzf;          // :560 as countdowns to the node face
                 left -= 1.0f;
-                go = (fminf(fminf(fminf(nx, ny), nz), left) != 0.0f) & more;
+                go = fminf(fminf(fminf(nx, ny), nz), left) != 0.0f;
                 VRC_STAT(w_iters, 1);
             } while (go);
             const int it = it_limit - (int)left;          // iterations this lane executed in the burst
@@ -230,15 +272,15 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                 r.distance_traveled += it - 1;            // the leaving iteration's :714 comes after the lookup
             } else {
                 r.distance_traveled += it;                // :714
-                if (it == it_limit) mode = kDone;         // :357
+                if (it == true_limit) mode = kDone;       // :357
             }
         }
-        unsigned long long ev = __ballot(mode == kEvent);
+        const unsigned long long ev = __ballot(mode == kEvent);
         const unsigned long long st = __ballot(mode == kStep);
         unsigned long long sh = __ballot(mode == kShade);
         if ((ev | st | sh) == 0ULL) break;
 
-        // ---- node events
+        // ---- phase 3: node events
         if (ev != 0ULL) {
             VRC_STAT(w_ev_passes, 1); VRC_STAT(w_ev_lanes, __popcll(ev));
             if (mode == kEvent) {
@@ -269,7 +311,8 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
             sh = __ballot(mode == kShade);
         }
 
-        // ---- hit block (:575-711): expensive and needed ~twice per pixel
+        // ---- phase 4: hit block (:575-711): expensive and needed ~twice per pixel, so it runs only when
+        // many lanes wait for it or nothing cheaper is left to do
         if (sh != 0ULL && (__ballot(mode == kStep) == 0ULL || __popcll(sh) >= shade_threshold)) {
             VRC_STAT(w_sh_passes, 1); VRC_STAT(w_sh_lanes, __popcll(sh));
             if (mode == kShade) {
@@ -278,6 +321,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                     mode = kDone;
                 } else {
                     enter_single();
+                    if (kJump) jump_cache_reset(jcache);  // delta_t changed with the redirect
                     r.distance_traveled++;                // :714
                     mode = (r.distance_traveled < r.max_distance && r.bounce_count < 2) ? kStep : kDone;   // :357
                 }
@@ -301,6 +345,9 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
     if (w_ev_lanes) atomicAdd(&block_ctr[kCtrEventLanes], (unsigned long long)w_ev_lanes);
     if (w_sh_passes) atomicAdd(&block_ctr[kCtrShadePasses], (unsigned long long)w_sh_passes);
     if (w_sh_lanes) atomicAdd(&block_ctr[kCtrShadeLanes], (unsigned long long)w_sh_lanes);
+    if (l_try) atomicAdd(&block_ctr[kCtrShadeLanes + 1], (unsigned long long)l_try);
+    if (l_ok) atomicAdd(&block_ctr[kCtrShadeLanes + 2], (unsigned long long)l_ok);
+    if (l_cov) atomicAdd(&block_ctr[kCtrMap], (unsigned long long)l_cov);
 #endif
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
     publish_counters(p, block_ctr, vals);
@@ -358,7 +405,10 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
     if (p.svo) {
         const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
         const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t) + (size_t)p.lds_pad_bytes;
-        hipLaunchKernelGGL(raycast_svo_kernel, dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+        if (p.jump_min_run < (1 << 24))
+            hipLaunchKernelGGL(raycast_svo_kernel<true>, dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+        else
+            hipLaunchKernelGGL(raycast_svo_kernel<false>, dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
     } else {
         hipLaunchKernelGGL(raycast_array_kernel, dim3(nblocks), dim3(kBlockThreads), 0, stream, p);
     }

@@ -399,8 +399,9 @@ int vrc_compute_async(vrc_caster *h) {
     p.max_distance = (int32_t)setting_or(h, "max_distance", 20);
     p.shadow_rays = (int32_t)setting_or(h, "shadow_rays", 1);
     // wave scheduling knobs of the SVO kernel; they never change results
-    p.event_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "event_threshold", 6)));
+    p.burst_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "burst_steps", 48)));
     p.shade_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "shade_threshold", 64)));
+    p.jump_min_run = (int32_t)std::min<int64_t>(1 << 24, std::max<int64_t>(1, setting_or(h, "jump_min_run", 1 << 24)));
     p.xcd_mode = (int32_t)setting_or(h, "xcd_mode", 1);
     p.lds_pad_bytes = (int32_t)std::min<int64_t>(120 * 1024, std::max<int64_t>(0, setting_or(h, "lds_pad_bytes", 0)));
     p.frame = h->d_frame;
