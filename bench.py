@@ -116,26 +116,47 @@ def algorithmic_bytes(ctr: dict, pixels: int, written: int) -> int:
     return 16 * pixels + 16 * written + 8 * ctr["descriptor_reads"] + 16 * ctr["texel_reads"] + ctr["map_reads"]
 
 
-def cpu_baseline(sc, width, height, stride=4):
-    """The CPU oracle ("port" of the kernel: DDA + atlas + Blinn-Phong + shadow) timed on the host
-    cores over every `stride`-th row of the same frame."""
+def usable_cores() -> int:
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(sc, width, height, gpu_frame=None):
+    """The CPU oracle ("port" of the kernel: DDA + atlas + Blinn-Phong + shadow) timed on ALL host cores
+    (OpenMP over rows) on the same frame.  The sample is bounded: the whole frame when the host has enough
+    cores to finish ~170 core-seconds of work in seconds, otherwise every k-th row.  Since the oracle frame
+    is there anyway it also checks the GPU frame (checker role only)."""
     from oracle import orc   # cpu_baseline leg only
-    cores = os.cpu_count() or 1
-    rows = list(range(0, height, stride))
-    rays = 0
-    t0 = time.perf_counter()
-    # one call per row keeps the sample bounded; OpenMP inside orc_raycast spreads each row's pixels...
-    # rows are independent, so hand a contiguous block per call and let OpenMP schedule rows
-    img = None
-    for y in rows:
+    cores = usable_cores()
+    stride = max(1, int(round(170.0 / (cores * 20.0))))        # whole frame ~170 core-seconds: keep the sample near 20 s
+    rays, secs, same, rows_done = 0, 0.0, True, 0
+    # bands of `cores` rows (one row per thread), spread evenly over the frame
+    band = height if stride == 1 else cores
+    starts = [0] if stride == 1 else list(range(0, height, band * stride))
+    for y in starts:
+        y1 = min(height, y + band)
+        t0 = time.perf_counter()
         img, _, ctr = orc.raycast(width=width, height=height, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"],
                                   lights=sc["lights"], atlas=sc["atlas"], tile_dim=(16, 16),
                                   descriptors=sc["octree"].descriptor_buffer, root_index=sc["octree"].root_index,
                                   octree_dim=sc["dim"], using_octree=0, max_distance=3 * sc["dim"],
-                                  rows=(y, min(y + 1, height)), threads=1, want_hits=False)
+                                  rows=(y, y1), threads=cores, want_hits=False)
+        secs += time.perf_counter() - t0
         rays += ctr["primary_rays"] + ctr["shadow_rays"]
-    dt = time.perf_counter() - t0
-    return rays, dt, cores, len(rows)
+        rows_done += y1 - y
+        if gpu_frame is not None:
+            same = same and bool(np.array_equal(img[y:y1].view(np.uint32), gpu_frame[y:y1].view(np.uint32)))
+    return rays, secs, cores, (os.cpu_count() or cores), rows_done, same
 
 
 def main():
@@ -232,10 +253,11 @@ def main():
                          "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            rays, secs, cores, nrows = cpu_baseline(sc, W, H, stride=8)
-            out["cpu_baseline"] = {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-                                   "sample": f"{nrows} of {H} rows (every 8th) of the same frame, oracle/vrc_oracle.c "
-                                             f"scalar, 1 thread of {cores}; {rays} rays in {secs:.2f} s"}
+            rays, secs, used, cores, nrows, same = cpu_baseline(sc, W, H, gpu_frame=c.read_image())
+            out["cpu_baseline"] = {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": used, "kind": "port",
+                                   "sample": f"{nrows} of {H} rows of the same frame, oracle/vrc_oracle.c (scalar C, OpenMP over rows), "
+                                             f"{used} of {cores} host threads; {rays} rays in {secs:.2f} s",
+                                   "gpu_frame_bit_identical_on_sample": same}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
