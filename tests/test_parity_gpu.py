@@ -143,6 +143,64 @@ def test_exact_jump_kernel_headline_frame():
     assert c.counters() == ctr
 
 
+EDGE_CASES = [
+    # name, dim, camera position, camera direction, max_distance
+    ("camera_outside_map", 16, (-3.4, 5.3, 6.2), (1.8, 0.3), 40),
+    ("camera_above_map", 16, (7.3, 8.6, 19.7), (2.6, 1.1), 40),
+    ("camera_on_integer_coordinates", 16, (8.0, 3.0, 9.0), (2.0, 1.5708), 40),
+    ("zero_step_cap", 16, (8.4, 3.3, 9.2), (2.0, 1.5708), 0),
+    ("one_step_cap", 16, (8.4, 3.3, 9.2), (2.0, 1.5708), 1),
+    ("tiny_map_dim2", 2, (0.6, 0.4, 1.3), (2.2, 0.9), 8),
+    ("tiny_map_dim4", 4, (1.6, 0.4, 3.3), (2.2, 0.9), 12),
+    ("camera_inside_solid", 32, (16.5, 16.5, 1.5), (1.2, 2.0), 96),
+]
+
+
+@pytest.mark.parametrize("using_octree", [1, 0], ids=["array", "svo"])
+@pytest.mark.parametrize("case", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
+def test_edge_cases(case, using_octree, atlas):
+    name, dim, cam_pos, cam_dir, md = case
+    rng = np.random.default_rng(dim)
+    g = (rng.random((dim, dim, dim)) < 0.15).astype(np.int8) * 5
+    g[0:max(1, dim // 8)] = 5
+    g = g.reshape(-1)
+    o = vrc.Octree.Generate(g, dim, buffer_size=100000)
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, dim * 0.7, dim * 0.3, dim * 0.9, -1, -1, -1.5]], dtype=np.float32)
+    w, h = 72, 40
+    c = make_caster(o, dim, using_octree, cam_dir, cam_pos, lights, atlas, w, h, md, grid=g)
+    assert c.compute(), c.last_error()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas,
+                                    tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                    octree_dim=dim, using_octree=using_octree, grid=g, max_distance=md)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+
+
+def test_non_cubic_dense_map(atlas):
+    """The array branch takes any dx,dy,dz (kernel index x + dx*(y + dz*z), ray_caster_kernel.cl:569)."""
+    dx, dy, dz = 24, 16, 16                       # dy == dz keeps the reference's dim.z-as-y-stride quirk in bounds
+    g = np.zeros((dz, dy, dx), dtype=np.int8)
+    g[0:2] = 5
+    g[2:9, 8, 12] = 6
+    g = g.reshape(-1)
+    o = vrc.Octree.Generate(np.zeros(16 ** 3, dtype=np.int8), 16, buffer_size=100000)   # bias source only
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, 20.0, 3.0, 14.0, -1, -1, -1.5]], dtype=np.float32)
+    w, h, md = 80, 48, 60
+    c = vrc.CLCaster()
+    assert c.init(0)
+    assert c.add_to_settings_buffer("octree_dimensions", "OCTDIM", 16) and c.add_to_settings_buffer("using_octree", "OCTENABLED", 1)
+    assert c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", md)
+    assert c.assign_octree(o) and c.assign_map(g, (dx, dy, dz))
+    cd, cp = np.array([1.9, 1.2], np.float32), np.array([3.3, 2.4, 9.6], np.float32)
+    li = np.zeros((8, 10), np.float32); li[0] = lights[0]
+    assert c.assign_camera(cd, cp) and c.create_viewport(w, h) and c.assign_lights(li) and c.create_texture_atlas(atlas, (16, 16))
+    assert c.validate(), c.last_error()
+    assert c.compute()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cd, cam_pos=cp, lights=li, atlas=atlas, tile_dim=(16, 16),
+                                    descriptors=o.descriptor_buffer, root_index=o.root_index, octree_dim=16, using_octree=1,
+                                    grid=g, map_dim=(dx, dy, dz), max_distance=md)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+
+
 def test_primary_only_and_live_camera(atlas):
     s = scenes.floor_pillars()
     dim = s["dim"]
