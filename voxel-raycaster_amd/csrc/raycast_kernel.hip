@@ -163,13 +163,36 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
         const uint64_t a = p.attachments[p.attach_lookup[node]];
         return (int)(int8_t)(a >> (8 * ((x & 1) | ((y & 1) << 1) | ((z & 1) << 2))));
     };
-    // park the ray in the empty node of size 2^b around its voxel
+    const bool widen = p.widen_nodes != 0;
+    // park the ray in the empty node of size 2^b around its voxel.  The parent's valid mask is at hand, so the
+    // box is widened over empty siblings that lie ahead of the ray: fewer node events, same lookups (a sibling
+    // the mask calls empty would have been found empty without any descriptor read).
     auto enter_node = [&](int b) {
-        const int size = 1 << b, low = ~(size - 1);
-        const int cx = r.vx & low, cy = r.vy & low, cz = r.vz & low;
-        bx = r.sx > 0 ? cx + size : cx - 1;
-        by = r.sy > 0 ? cy + size : cy - 1;
-        bz = r.sz > 0 ? cz + size : cz - 1;
+        const int size = 1 << b;
+        const unsigned valid = (unsigned)cur & 0xffu;
+        const int i = ((r.vx >> b) & 1) | (((r.vy >> b) & 1) << 1) | (((r.vz >> b) & 1) << 2);
+        // axis a can be widened when the ray moves from this half of the parent toward the other half
+        const unsigned ahead = (((i & 1) == 0) == (r.sx > 0) ? 1u : 0u) | ((((i >> 1) & 1) == 0) == (r.sy > 0) ? 2u : 0u) |
+                               ((((i >> 2) & 1) == 0) == (r.sz > 0) ? 4u : 0u);
+        auto span = [&](unsigned e) -> unsigned {                 // children covered when widening over the axes in e
+            unsigned m = 1u << i;
+            if (e & 1u) m |= ((m & 0x55u) << 1) | ((m & 0xaau) >> 1);
+            if (e & 2u) m |= ((m & 0x33u) << 2) | ((m & 0xccu) >> 2);
+            if (e & 4u) m |= ((m & 0x0fu) << 4) | ((m & 0xf0u) >> 4);
+            return m;
+        };
+        unsigned ext = 0;
+        if (widen) {
+            if ((span(ahead) & valid) == 0) ext = ahead;
+            else if ((ahead & 2u) && (span(2u) & valid) == 0) ext = 2u;
+            else if ((ahead & 1u) && (span(1u) & valid) == 0) ext = 1u;
+            else if ((ahead & 4u) && (span(4u) & valid) == 0) ext = 4u;
+        }
+        const int sx2 = (ext & 1u) ? 2 * size : size, sy2 = (ext & 2u) ? 2 * size : size, sz2 = (ext & 4u) ? 2 * size : size;
+        const int cx = r.vx & ~(sx2 - 1), cy = r.vy & ~(sy2 - 1), cz = r.vz & ~(sz2 - 1);
+        bx = r.sx > 0 ? cx + sx2 : cx - 1;
+        by = r.sy > 0 ? cy + sy2 : cy - 1;
+        bz = r.sz > 0 ? cz + sz2 : cz - 1;
         nx = (float)((bx - r.vx) * r.sx); ny = (float)((by - r.vy) * r.sy); nz = (float)((bz - r.vz) * r.sz);
     };
     // extent unknown (after a redirect, or inside solid): force an event after one step

@@ -58,6 +58,7 @@ struct RaycastParams {
     int32_t shadow_rays;
     int32_t burst_steps;              // SVO kernel: ordinary DDA steps per lane and round before node events are serviced
     int32_t shade_threshold;          // ... and before the hit block runs
+    int32_t widen_nodes;              // widen an empty node over empty siblings ahead of the ray (results unchanged)
     int32_t jump_min_run;             // opt-in: exact closed-form jumps for stretches of at least this many steps (1<<24 = off)
     int32_t lds_pad_bytes;            // experiment knob: extra dynamic LDS to lower occupancy
     int32_t xcd_mode;                 // block->tile map: 0 contiguous eighth per XCD, 1 tile rows interleaved over XCDs, 2 none
