@@ -183,10 +183,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
+    # test hook (tests/ and rehearsals on a 1-GPU box only): let several ranks share GPU 0 over gloo so that the
+    # N>1 code path -- supersampled ray table, row tiling, SUM/MAX reductions -- can be exercised without 8 GPUs
+    rehearsal = os.environ.get("VRC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL: barrier + scalar reductions only
+        # RCCL: barrier + scalar reductions only
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
 
     import __graft_entry__ as graft
     if rank == 0:

@@ -354,3 +354,23 @@ def test_headline_config_full_size_properties():
         assert c.set_row_tiling(r, 2, 8) and c.compute()
         frames.append(c.read_image())
     assert np.array_equal(frames[1].view(np.uint32), img.view(np.uint32))   # same buffer: both halves rewritten
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N>1 path (supersampled ray table, interleaved row tiling, SUM/MAX reductions, one JSON line)
+    with two ranks sharing GPU 0 over gloo -- the driver's real multi-GPU launch uses RCCL on 2/4/8 GPUs."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, VRC_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--depth", "8", "--width", "320", "--height", "240"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["rays_per_step"] > 2 * 320 * 240          # both ranks' rays are counted
+    assert rec["roofline"]["bound"] == "hbm" and "cpu_baseline" not in rec
