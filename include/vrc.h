@@ -233,6 +233,14 @@ int vrc_octree_get_voxel(const uint64_t *descriptors, uint64_t root_index, uint3
                          const int32_t position[3], int32_t *found, int32_t *resolution,
                          int32_t sub_oct_pos[3]);
 
+/* Octree::Load (declared, never defined: include/map/Octree.h:38) and its counterpart: a flat little-endian
+ * file of the descriptor array (+ optional attachment buffers).  Loaded arrays are malloc'ed (vrc_free).      */
+int vrc_octree_save(const char *path, uint32_t dim, const uint64_t *descriptors, uint64_t n_descriptors,
+                    uint64_t root_index, const uint32_t *lookup, const uint64_t *attachments,
+                    uint64_t n_attachments);
+int vrc_octree_load(const char *path, uint32_t *dim, uint64_t **descriptors, uint64_t *n_descriptors,
+                    uint64_t *root_index, uint32_t **lookup, uint64_t **attachments, uint64_t *n_attachments);
+
 void vrc_free(void *p);
 
 #ifdef __cplusplus

@@ -113,6 +113,28 @@ def test_sparse_terrain_builder_equals_dense_builder(depth):
     assert height.min() >= dim // 4 and height.max() < 3 * dim // 4 + 1
 
 
+def test_octree_save_load_roundtrip(tmp_path):
+    rng = np.random.default_rng(21)
+    g = (rng.random(32 ** 3) < 0.1).astype(np.int8) * 5
+    g[rng.integers(0, g.size, 50)] = 6
+    o = vrc.Octree.Generate(g, 32, buffer_size=0, strict_reference=False).attach_materials_from_grid(g)
+    path = str(tmp_path / "scene.svo")
+    o.Save(path)
+    q = vrc.Octree.Load(path)
+    assert q.dim == 32 and q.root_index == o.root_index
+    assert np.array_equal(q.descriptor_buffer, o.descriptor_buffer)
+    assert np.array_equal(q.attachment_lookup, o.attachment_lookup) and np.array_equal(q.attachment_buffer, o.attachment_buffer)
+    bare = vrc.Octree.Generate(g, 32)
+    bare.Save(path)
+    assert vrc.Octree.Load(path).attachment_buffer is None
+    with open(path, "r+b") as f:
+        f.write(b"garbage!")
+    with pytest.raises(vrc.VrcError):
+        vrc.Octree.Load(path)
+    with pytest.raises(vrc.VrcError):
+        vrc.Octree.Load(str(tmp_path / "missing.svo"))
+
+
 # ---------------------------------------------------------------- a4 ray table
 def test_viewport_table():
     assert math.sin(1.57).hex() == "0x1.fffff55c67bb1p-1"         # the double constants of CLCaster.cpp:253-255

@@ -93,6 +93,9 @@ SIGNATURES = {
     "vrc_scene_shell_terrain_dense": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, _i8p]),
     "vrc_scene_atlas": (C.c_int, [C.c_int32, C.c_int32, _u8p]),
     "vrc_octree_get_voxel": (C.c_int, [_u64p, C.c_uint64, C.c_uint32, _i32p, _i32p, _i32p, _i32p]),
+    "vrc_octree_save": (C.c_int, [C.c_char_p, C.c_uint32, _u64p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), _u64p, C.c_uint64]),
+    "vrc_octree_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(_u64p), _u64p, _u64p,
+                                  C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(_u64p), _u64p]),
     "vrc_free": (None, [C.c_void_p]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
@@ -165,6 +168,30 @@ class Octree:
             raise VrcError(f"vrc_scene_shell_terrain_attachments: {STATUS.get(rc, rc)}")
         self._take_attachments(lp, ap, n.value)
         return self
+
+    def Save(self, path: str) -> None:
+        has = self.attachment_lookup is not None and self.attachment_buffer is not None
+        rc = lib.vrc_octree_save(path.encode(), self.dim, _ptr(self.descriptor_buffer, _u64p), self.descriptor_buffer.size,
+                                 self.root_index, _ptr(self.attachment_lookup, C.POINTER(C.c_uint32)) if has else None,
+                                 _ptr(self.attachment_buffer, _u64p) if has else None,
+                                 self.attachment_buffer.size if has else 0)
+        if rc != 0:
+            raise VrcError(f"vrc_octree_save: {STATUS.get(rc, rc)}")
+
+    @classmethod
+    def Load(cls, octree_file_name: str) -> "Octree":
+        """Octree::Load (include/map/Octree.h:38)."""
+        dim, n, root, na = C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        dp, lp, ap = _u64p(), C.POINTER(C.c_uint32)(), _u64p()
+        rc = lib.vrc_octree_load(octree_file_name.encode(), C.byref(dim), C.byref(dp), C.byref(n), C.byref(root),
+                                 C.byref(lp), C.byref(ap), C.byref(na))
+        if rc != 0:
+            raise VrcError(f"vrc_octree_load: {STATUS.get(rc, rc)}")
+        o = cls(np.ctypeslib.as_array(dp, shape=(n.value,)).copy(), root.value, dim.value)
+        lib.vrc_free(dp)
+        if na.value:
+            o._take_attachments(lp, ap, na.value)
+        return o
 
     def GetVoxel(self, position):
         """Octree::GetVoxel (src/map/Octree.cpp:45-158): (found, resolution, sub_oct_pos)."""

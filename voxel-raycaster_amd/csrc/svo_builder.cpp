@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -411,6 +412,63 @@ int vrc_octree_get_voxel(const uint64_t *descriptors, uint64_t root_index, uint3
     if (found) *found = hit;
     if (resolution) *resolution = res;
     if (sub_oct_pos) for (int a = 0; a < 3; a++) sub_oct_pos[a] = corner[a];
+    return VRC_OK;
+}
+
+// ---- SVO (de)serialisation: Octree::Load is declared but never defined in the reference
+// (include/map/Octree.h:38, TODO src/main.cpp:30).  Little-endian file:
+//   char[8] "VRCSVO01" | u32 dim | u32 flags(bit0: attachments) | u64 root | u64 n_desc | u64 n_attach |
+//   u64 desc[n_desc] | (u32 lookup[n_desc] | u64 attach[n_attach])
+int vrc_octree_save(const char *path, uint32_t dim, const uint64_t *descriptors, uint64_t n_descriptors, uint64_t root_index,
+                    const uint32_t *lookup, const uint64_t *attachments, uint64_t n_attachments) {
+    if (!path || !descriptors || !is_pow2(dim) || root_index >= n_descriptors) return VRC_ERR_INVALID_ARGUMENT;
+    const bool with_att = lookup && attachments && n_attachments;
+    FILE *f = fopen(path, "wb");
+    if (!f) return VRC_ERR_NOT_FOUND;
+    const uint32_t flags = with_att ? 1u : 0u;
+    const uint64_t na = with_att ? n_attachments : 0;
+    bool ok = fwrite("VRCSVO01", 1, 8, f) == 8 && fwrite(&dim, 4, 1, f) == 1 && fwrite(&flags, 4, 1, f) == 1 &&
+              fwrite(&root_index, 8, 1, f) == 1 && fwrite(&n_descriptors, 8, 1, f) == 1 && fwrite(&na, 8, 1, f) == 1 &&
+              fwrite(descriptors, 8, (size_t)n_descriptors, f) == (size_t)n_descriptors;
+    if (ok && with_att)
+        ok = fwrite(lookup, 4, (size_t)n_descriptors, f) == (size_t)n_descriptors && fwrite(attachments, 8, (size_t)na, f) == (size_t)na;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? VRC_OK : VRC_ERR_DEVICE;
+}
+
+int vrc_octree_load(const char *path, uint32_t *dim, uint64_t **descriptors, uint64_t *n_descriptors, uint64_t *root_index,
+                    uint32_t **lookup, uint64_t **attachments, uint64_t *n_attachments) {
+    if (!path || !dim || !descriptors || !n_descriptors || !root_index) return VRC_ERR_INVALID_ARGUMENT;
+    *descriptors = nullptr;
+    if (lookup) *lookup = nullptr;
+    if (attachments) *attachments = nullptr;
+    if (n_attachments) *n_attachments = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) return VRC_ERR_NOT_FOUND;
+    char magic[8];
+    uint32_t flags = 0;
+    uint64_t na = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "VRCSVO01", 8) == 0 && fread(dim, 4, 1, f) == 1 &&
+              fread(&flags, 4, 1, f) == 1 && fread(root_index, 8, 1, f) == 1 && fread(n_descriptors, 8, 1, f) == 1 &&
+              fread(&na, 8, 1, f) == 1 && is_pow2(*dim) && *n_descriptors > 0 && *root_index < *n_descriptors;
+    if (ok) {
+        *descriptors = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)*n_descriptors);
+        ok = *descriptors && fread(*descriptors, 8, (size_t)*n_descriptors, f) == (size_t)*n_descriptors;
+    }
+    if (ok && (flags & 1u) && lookup && attachments && n_attachments) {
+        *lookup = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)*n_descriptors);
+        *attachments = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(na ? na : 1));
+        ok = *lookup && *attachments && fread(*lookup, 4, (size_t)*n_descriptors, f) == (size_t)*n_descriptors &&
+             fread(*attachments, 8, (size_t)na, f) == (size_t)na;
+        *n_attachments = na;
+    }
+    fclose(f);
+    if (!ok) {
+        free(*descriptors); *descriptors = nullptr;
+        if (lookup) { free(*lookup); *lookup = nullptr; }
+        if (attachments) { free(*attachments); *attachments = nullptr; }
+        return VRC_ERR_INVALID_ARGUMENT;
+    }
     return VRC_OK;
 }
 
