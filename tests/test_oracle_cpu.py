@@ -27,6 +27,19 @@ def test_cabi_exports_every_declared_symbol():
         assert name in vrc.SIGNATURES, f"python binding lacks {name}"
 
 
+def test_c_consumer(tmp_path):
+    """include/vrc.h is plain C99 and a C program can drive libvrc.so (host-only entry points here)."""
+    import subprocess
+    inc, pkg = os.path.join(ROOT, "include"), os.path.join(ROOT, "voxel-raycaster_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c", os.path.join(inc, "vrc.h")])
+    exe = str(tmp_path / "cabi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + inc, os.path.join(ROOT, "tests", "cabi_smoke.c"), "-o", exe,
+                           "-L" + pkg, "-lvrc", "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, f"cabi_smoke failed at check {out.returncode}: {out.stdout} {out.stderr}"
+    assert "c-abi ok" in out.stdout
+
+
 def test_no_gpu_means_loud_failure(gpu_available):
     if gpu_available:
         pytest.skip("a GPU is present")
