@@ -193,7 +193,9 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
         bx = r.sx > 0 ? cx + sx2 : cx - 1;
         by = r.sy > 0 ? cy + sy2 : cy - 1;
         bz = r.sz > 0 ? cz + sz2 : cz - 1;
-        nx = (float)((bx - r.vx) * r.sx); ny = (float)((by - r.vy) * r.sy); nz = (float)((bz - r.vz) * r.sz);
+        // countdown = |base - voxel| (the step is +-1: no multiply needed)
+        nx = (float)(r.sx > 0 ? bx - r.vx : r.vx - bx); ny = (float)(r.sy > 0 ? by - r.vy : r.vy - by);
+        nz = (float)(r.sz > 0 ? bz - r.vz : r.vz - bz);
     };
     // extent unknown (after a redirect, or inside solid): force an event after one step
     auto enter_single = [&]() {
@@ -307,7 +309,9 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
         if (ev != 0ULL) {
             VRC_STAT(w_ev_passes, 1); VRC_STAT(w_ev_lanes, __popcll(ev));
             if (mode == kEvent) {
-                r.vx = bx - r.sx * (int)nx; r.vy = by - r.sy * (int)ny; r.vz = bz - r.sz * (int)nz;
+                r.vx = r.sx > 0 ? bx - (int)nx : bx + (int)nx;   // voxel = base - step * countdown, step = +-1
+                r.vy = r.sy > 0 ? by - (int)ny : by + (int)ny;
+                r.vz = r.sz > 0 ? bz - (int)nz : bz + (int)nz;
                 r.fmx = (int)fxf; r.fmy = (int)fyf; r.fmz = (int)fzf;
                 if (r.vx >= p.map_dim[0] || r.vy >= p.map_dim[1] || r.vz >= p.map_dim[2] || r.vx < 0 || r.vy < 0 || r.vz < 0) {
                     oob_exit(r);                          // :563-568
