@@ -356,6 +356,36 @@ def test_headline_config_full_size_properties():
     assert np.array_equal(frames[1].view(np.uint32), img.view(np.uint32))   # same buffer: both halves rewritten
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_random_scenes(seed, atlas):
+    """Seeded random scenes: dims 4..32, materials {0,1,5,6}, cameras inside/outside/on the grid, random lights,
+    ragged resolutions, random step caps; array kernel, SVO kernel (+attachments) and the jump kernel vs the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.choice([4, 8, 16, 32]))
+    dens = float(rng.choice([0.02, 0.1, 0.4]))
+    g = rng.choice(np.array([0, 1, 5, 6], dtype=np.int8), size=dim ** 3, p=[1 - dens, dens * 0.1, dens * 0.7, dens * 0.2])
+    if rng.random() < 0.5:
+        g.reshape(dim, dim, dim)[0:max(1, dim // 8)] = 5
+    cam_pos = tuple(float(v) for v in (rng.random(3) * (dim + 4) - 2))
+    if rng.random() < 0.2:
+        cam_pos = tuple(float(int(v)) for v in cam_pos)               # on integer coordinates
+    cam_dir = (float(rng.random() * 3.0 + 0.1), float(rng.random() * 6.2))
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, *(rng.random(3) * dim * 1.2), -1, -1, -1.5]], dtype=np.float32)
+    w, h = int(rng.integers(9, 90)), int(rng.integers(9, 60))
+    md = int(rng.choice([0, 1, 7, 20, 3 * dim]))
+    o = vrc.Octree.Generate(g, dim, buffer_size=100000).attach_materials_from_grid(g)
+    for using_octree, jump in ((1, False), (0, False), (0, True)):
+        c = make_caster(o, dim, using_octree, cam_dir, cam_pos, lights, atlas, w, h, md, grid=g)
+        if jump:
+            assert c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 2)
+        assert c.compute(), c.last_error()
+        kw = dict(attachment_lookup=o.attachment_lookup, attachments=o.attachment_buffer) if not using_octree else {}
+        oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas,
+                                        tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                        octree_dim=dim, using_octree=using_octree, grid=g, max_distance=md, **kw)
+        assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+
+
 def test_bench_two_rank_rehearsal():
     """bench.py's N>1 path (supersampled ray table, interleaved row tiling, SUM/MAX reductions, one JSON line)
     with two ranks sharing GPU 0 over gloo -- the driver's real multi-GPU launch uses RCCL on 2/4/8 GPUs."""
