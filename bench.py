@@ -159,6 +159,21 @@ def cpu_baseline(sc, width, height, gpu_frame=None):
     return rays, secs, cores, (os.cpu_count() or cores), rows_done, same
 
 
+def ray_cpp_baseline():
+    """BASELINE configs[0]: the reference's own CPU caster src/Ray.cpp (restated, its two stubbed lines restored)
+    on the 256^3 dense twin of the scene at 640x480, primary rays only, all usable host cores."""
+    from oracle import orc   # cpu_baseline leg only
+    import voxel_raycaster_amd as vrc
+    sc = build_scene(8)
+    grid = vrc.shell_terrain_dense(8, seed=1, thickness=2)
+    cores = usable_cores()
+    t0 = time.perf_counter()
+    _, steps = orc.ray_cast_frame(grid, (256, 256, 256), 640, 480, sc["cam_dir"], sc["cam_pos"], threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(640 * 480 / dt / 1e6, 4), "unit": "Mrays/s (primary only)", "cores": cores,
+            "workload": "configs[0]: 256^3 dense grid, 640x480, Ray::Cast restated (600-step cap)", "dda_steps": steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,7 +278,8 @@ def main():
             out["cpu_baseline"] = {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": used, "kind": "port",
                                    "sample": f"{nrows} of {H} rows of the same frame, oracle/vrc_oracle.c (scalar C, OpenMP over rows), "
                                              f"{used} of {cores} host threads; {rays} rays in {secs:.2f} s",
-                                   "gpu_frame_bit_identical_on_sample": same}
+                                   "gpu_frame_bit_identical_on_sample": same,
+                                   "ray_cpp": ray_cpp_baseline()}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -195,3 +195,20 @@ def ray_cast(grid, dim, origin, direction, as_written=True):
     steps = C.c_int32()
     col = lib.orc_ray_cast(_p(g, _i8p), d, o, r, int(as_written), C.byref(steps))
     return (col & 255, (col >> 8) & 255, (col >> 16) & 255, (col >> 24) & 255), int(steps.value)
+
+
+lib.orc_ray_cast_frame.restype = C.c_int64
+lib.orc_ray_cast_frame.argtypes = [_i8p, _i32p, C.c_int32, C.c_int32, _f32p, _f32p, _f32p, C.POINTER(C.c_uint32), C.c_int]
+
+
+def ray_cast_frame(grid, dim, width, height, cam_dir, cam_pos, threads=1):
+    """Ray::Cast (restored) for every pixel of a frame; returns (rgba uint32[h,w], total DDA steps)."""
+    g = np.ascontiguousarray(grid, dtype=np.int8).reshape(-1)
+    d = (C.c_int32 * 3)(*dim)
+    vp = create_viewport(width, height)
+    trig = camera_trig(np.asarray(cam_dir, dtype=np.float32))
+    pos = np.asarray(cam_pos, dtype=np.float32)
+    out = np.zeros((height, width), dtype=np.uint32)
+    steps = lib.orc_ray_cast_frame(_p(g, _i8p), d, width, height, _p(vp, _f32p), _p(trig, _f32p), _p(pos, _f32p),
+                                   _p(out, C.POINTER(C.c_uint32)), threads)
+    return out, int(steps)

@@ -765,3 +765,27 @@ uint32_t orc_ray_cast(const int8_t *map, const int32_t dim_in[3], const float or
     } while (dist < 600);                                         /* :143 */
     return rgba(0, 255, 255, 255);                                /* sf::Color::Cyan */
 }
+
+int64_t orc_ray_cast_frame(const int8_t *map, const int32_t dim[3], int32_t width, int32_t height,
+                           const float *viewport_matrix, const float cam_trig[4], const float cam_pos[3],
+                           uint32_t *out, int threads) {
+    int64_t total = 0;
+    const float s1 = cam_trig[0], c1 = cam_trig[1], s2 = cam_trig[2], c2 = cam_trig[3];
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1) reduction(+ : total)
+#endif
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const float *pm = viewport_matrix + 4 * ((int64_t)x + (int64_t)width * y);
+            float d[3];
+            {   /* same pitch / yaw as the kernel (:280-291) so both CPU paths see the same rays */
+                float px = pm[2] * s1 + pm[0] * c1, py = pm[1], pz = pm[2] * c1 - pm[0] * s1;
+                d[0] = px * c2 - py * s2; d[1] = px * s2 + py * c2; d[2] = pz;
+            }
+            int32_t steps = 0;
+            out[(int64_t)x + (int64_t)width * y] = orc_ray_cast(map, dim, cam_pos, d, 0, &steps);
+            total += steps;
+        }
+    (void)threads;
+    return total;
+}

@@ -165,6 +165,13 @@ void orc_image_to_rgba8(const float *image, uint8_t *out, int64_t n_pixels);
 uint32_t orc_ray_cast(const int8_t *map, const int32_t dim[3], const float origin[3],
                       const float direction[3], int as_written, int32_t *steps_out);
 
+/* Ray::Cast over a whole frame (one primary ray per pixel, rays = the a4 table rotated like :276-291),
+ * restored variant, OpenMP over rows: the "src/Ray.cpp CPU path" BASELINE.json names as the CPU comparison.
+ * out: packed RGBA per pixel.  Returns the total number of DDA steps.                                       */
+int64_t orc_ray_cast_frame(const int8_t *map, const int32_t dim[3], int32_t width, int32_t height,
+                           const float *viewport_matrix, const float cam_trig[4], const float cam_pos[3],
+                           uint32_t *out, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -275,6 +275,26 @@ def test_ray_cast_restored_hits_floor():
     assert col[:3] == (255, 120, 255) and 8 <= steps <= 12
 
 
+def test_ray_cast_frame_matches_single_rays():
+    dim = 16
+    g = np.zeros((dim, dim, dim), dtype=np.int8)
+    g[0:2] = 5
+    g[2:6, 8, 8] = 6
+    cam_dir, cam_pos = (2.0, 1.5708), (8.37, 2.41, 9.29)
+    img, steps = orc.ray_cast_frame(g.reshape(-1), (dim, dim, dim), 32, 24, cam_dir, cam_pos, threads=2)
+    vp, trig = orc.create_viewport(32, 24), orc.camera_trig(np.array(cam_dir, np.float32))
+    total = 0
+    for (x, y) in [(0, 0), (16, 12), (31, 23), (5, 20)]:
+        p = vp[y, x]
+        px, py, pz = p[2] * trig[0] + p[0] * trig[1], p[1], p[2] * trig[1] - p[0] * trig[0]
+        d = (np.float32(px * trig[3] - py * trig[2]), np.float32(px * trig[2] + py * trig[3]), np.float32(pz))
+        col, st = orc.ray_cast(g.reshape(-1), (dim, dim, dim), cam_pos, d, as_written=False)
+        packed = col[0] | (col[1] << 8) | (col[2] << 16) | (col[3] << 24)
+        assert int(img[y, x]) == packed
+        total += st
+    assert steps >= total and {int(v) & 0xFFFFFF for v in np.unique(img)} <= {0xFF78FF, 0xDC5096, 0xFBF5AC, 0xFFFF00}
+
+
 # ---------------------------------------------------------------- committed regression vectors
 @pytest.mark.skipif(not GOLDEN, reason="tests/golden/orc_*.npz missing")
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
