@@ -317,6 +317,26 @@ def test_baseline_configs_sampled_rows(depth, w, h):
         assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
 
 
+def test_depth13_scene_sampled_rows():
+    """Beyond the headline: 8192^3 (depth 13), 84 M descriptors (674 MB), thousands of far pointers and page
+    headers, 12 stack levels in LDS -- sampled rows bit-exact vs the oracle, counters consistent."""
+    sc = _bench_scene(13)
+    w, h, dim = 1920, 1080, sc["dim"]
+    d = sc["octree"].descriptor_buffer
+    far = ((d >> np.uint64(15)) & np.uint64(1)).astype(bool) & (d != np.uint64(0xFFFFFFFFFFFFFFFF))
+    assert far.sum() > 1000 and (d == np.uint64(0xFFFFFFFFFFFFFFFF)).sum() > 1000
+    c = make_caster(sc["octree"], dim, 0, sc["cam_dir"], sc["cam_pos"], sc["lights"], sc["atlas"], w, h, 3 * dim)
+    assert c.compute(), c.last_error()
+    img, hits, ctr = c.read_image(), c.read_hits(), c.counters()
+    assert ctr["descriptor_reads"] == int(hits[..., 7].sum()) and ctr["primary_rays"] == w * h
+    for y0 in range(37, h, 131):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=c._li,
+                                     atlas=sc["atlas"], tile_dim=(16, 16), descriptors=d, root_index=sc["octree"].root_index,
+                                     octree_dim=dim, using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=8)
+        assert np.array_equal(hits[y0], ohits[y0])
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+
+
 def test_headline_config_full_size_properties():
     """BASELINE configs[2] at full size (depth-12 SVO, 1920x1080, primary + shadow + shading):
     sampled rows bit-exact vs the oracle, idempotence, tiling invariance, counter identities."""

@@ -20,3 +20,4 @@ run("C1 geometry (d8, 640x480, primary only) on the GPU", 8, 640, 480, 0)
 run("C2 (d10, 1080p, primary only)", 10, 1920, 1080, 0)
 run("C3 headline (d12, 1080p, primary+shadow)", 12, 1920, 1080, 1)
 run("C4 geometry (d12, 4K, 1 light) on 1 GPU", 12, 3840, 2160, 1)
+run("beyond BASELINE: d13 (8192^3), 1080p, primary+shadow", 13, 1920, 1080, 1)
