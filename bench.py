@@ -54,6 +54,10 @@ def build_scene(depth: int, seed: int = 1):
         cz = z0
     lights = np.zeros((8, 10), dtype=np.float32)
     lights[0] = [0.01, 0.01, 0.01, 0.2, dim / 4, dim / 4, 3 * dim / 4, -1.0, -1.0, -1.5]
+    # lights 1-3: only the multi-light extension reads them (setting light_count; BASELINE configs[3]/[4] geometry)
+    lights[1] = [0.02, 0.01, 0.00, 0.2, 3 * dim / 4 + 0.3, dim / 2 + 0.2, 5 * dim / 8 + 0.1, 0.0, 0.0, -1.0]
+    lights[2] = [0.00, 0.01, 0.02, 0.2, dim / 2 + 0.4, 7 * dim / 8 + 0.1, dim / 2 + 0.3, 0.0, 0.0, -1.0]
+    lights[3] = [0.01, 0.02, 0.01, 0.2, dim / 8 + 0.2, 5 * dim / 8 + 0.3, 7 * dim / 8 + 0.4, 0.0, 0.0, -1.0]
     return dict(depth=depth, dim=dim, octree=octree, height=height,
                 cam_pos=np.array([cx + 0.37, cy + 0.41, cz + 0.29], dtype=np.float32),
                 cam_dir=np.array([2.0, 1.5708], dtype=np.float32),
@@ -76,7 +80,7 @@ def supersampled_table(width: int, height: int, n: int) -> np.ndarray:
     return t
 
 
-def make_caster(sc, width, height, device, table=None, shadow_rays=1):
+def make_caster(sc, width, height, device, table=None, shadow_rays=1, light_count=1):
     import voxel_raycaster_amd as vrc
     c = vrc.CLCaster()
     if not c.init(device):
@@ -85,6 +89,7 @@ def make_caster(sc, width, height, device, table=None, shadow_rays=1):
           and c.add_to_settings_buffer("using_octree", "OCTENABLED", 0)
           and c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", 3 * sc["dim"])
           and c.add_to_settings_buffer("shadow_rays", "SHADOW_RAYS", shadow_rays)
+          and c.add_to_settings_buffer("light_count", "LIGHT_COUNT", light_count)
           and c.assign_octree(sc["octree"])
           and c.assign_camera(sc["cam_dir"], sc["cam_pos"])
           and (c.create_viewport(width, height) if table is None else c.create_viewport_table(table))

@@ -360,6 +360,51 @@ static int svo_locate(svo_cursor *c, const int32_t v[3]) {
     }
 }
 
+/* ---- the light part of the hit block (:657-679) for one light, from the FIRST STRIKE
+ * (primary hit): view_light, max_distance, redirect toward the light.  With one active light this is the
+ * reference's code at its place; with several (extension, SURVEY 8f-1, TODO src/main.cpp:33 "Multi light
+ * support via first-strike resetting") it is re-run from the stored strike for each further light.
+ * Returns 0 for the early return of :671-672 (pixel left unwritten).                                          */
+typedef struct {
+    int   voxel[3];        /* the solid voxel of the first strike */
+    float face_position[3];
+    int   nmask[3];        /* face_mask * voxel_step of the primary ray */
+    int   distance;        /* distance_traveled at the strike */
+} orc_strike;
+
+static int light_from_strike(const orc_scene *s, const float *L, const orc_strike *k, const float in_color[4],
+                             float color_accumulator[4], float rd[3], int voxel[3], int vstep[3],
+                             float delta_t[3], float it[3], int *max_distance, int cast) {
+    const float light_pos[3] = {L[4], L[5], L[6]};
+    const float light_rgbi[4] = {L[0], L[1], L[2], L[3]};
+    float hit_pos[3], to_light[3], to_view[3];
+    for (int a = 0; a < 3; a++) {
+        hit_pos[a] = (float)k->voxel[a] + k->face_position[a];
+        to_light[a] = hit_pos[a] - light_pos[a];
+        to_view[a] = hit_pos[a] - s->cam_pos[a];
+    }
+    float lit[4];
+    view_light(lit, in_color, to_light, light_rgbi, to_view, k->nmask);      /* :657-664 */
+    for (int c = 0; c < 4; c++) color_accumulator[c] = lit[c];
+    if (!cast) return 1;
+    {                                                 /* :667 int = int + float */
+        float dv[3] = {(float)k->voxel[0] - light_pos[0], (float)k->voxel[1] - light_pos[1],
+                       (float)k->voxel[2] - light_pos[2]};
+        *max_distance = (int)((float)k->distance + sqrtf(dot3(dv, dv)));
+    }
+    float lv[3] = {light_pos[0] - hit_pos[0], light_pos[1] - hit_pos[1], light_pos[2] - hit_pos[2]};
+    normalize3(lv, rd);                               /* :670 */
+    if (rd[0] == 0.0f || rd[1] == 0.0f || rd[2] == 0.0f) return 0;           /* :671-672 */
+    for (int a = 0; a < 3; a++) {
+        voxel[a] = k->voxel[a] - k->nmask[a];         /* :674 voxel -= voxel_step * face_mask */
+        vstep[a] = isign(rd[a]);                      /* :675 */
+        delta_t[a] = fabsf(1.0f / rd[a]);             /* :677 */
+        it[a] = delta_t[a] * (hit_pos[a] - floorf(hit_pos[a])) * (float)vstep[a];   /* :678 */
+        it[a] += delta_t[a] * -(it[a] < 0.0f ? -1.0f : 0.0f);                       /* :679 */
+    }
+    return 1;
+}
+
 /* ---- one pixel of `raycaster`  (kernels/ray_caster_kernel.cl:256-724) */
 static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias[3],
                           float *image, int32_t *hits, orc_counters *ctr) {
@@ -438,10 +483,15 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
             (void)svo_locate(&cur, voxel);
     }
 
-    const float *L = s->lights;
-    const float light_pos[3] = {L[4], L[5], L[6]};
-    const float light_rgbi[4] = {L[0], L[1], L[2], L[3]};
+    /* the reference reads light 0 only (:660-670); active_lights > 1 is the multi-light extension */
+    int nlights = s->active_lights < s->light_count ? s->active_lights : s->light_count;
+    if (nlights > 8) nlights = 8;                     /* LightController.h:95: 8 slots */
+    if (nlights < 1) nlights = 1;
+    int light_index = 0;
+    orc_strike strike;
+    memset(&strike, 0, sizeof(strike));
 
+    for (;;) {
     while (distance_traveled < max_distance && bounce_count < 2) {        /* :357 */
         ctr->n_steps++;
         /* :558 ties step several axes */
@@ -535,40 +585,26 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
                 ctr->n_tex++;
                 for (int c = 0; c < 3; c++) voxel_color[c] += texel[c] / 2.0f;
 
-                float hit_pos[3], to_light[3], to_view[3];
-                int nmask[3];
                 for (int a = 0; a < 3; a++) {
-                    hit_pos[a] = (float)voxel[a] + face_position[a];
-                    to_light[a] = hit_pos[a] - light_pos[a];
-                    to_view[a] = hit_pos[a] - s->cam_pos[a];
-                    nmask[a] = face_mask[a] * vstep[a];
+                    strike.voxel[a] = voxel[a];
+                    strike.face_position[a] = face_position[a];
+                    strike.nmask[a] = face_mask[a] * vstep[a];
                 }
-                view_light(color_accumulator, voxel_color, to_light, light_rgbi, to_view, nmask);
-
+                strike.distance = distance_traveled;
                 fog_distance = (float)distance_traveled;          /* :666 */
-                if (!s->shadow_rays) {          /* extension: primary rays only */
+                if (!s->shadow_rays) {          /* extension: primary rays only; every active light shades */
+                    for (int l = 0; l < nlights; l++)
+                        (void)light_from_strike(s, s->lights + 10 * l, &strike, l == 0 ? voxel_color : color_accumulator,
+                                                color_accumulator, rd, voxel, vstep, delta_t, it, &max_distance, 0);
                     break;
                 }
-                {                                                 /* :667 int = int + float */
-                    float dv[3] = {(float)voxel[0] - light_pos[0], (float)voxel[1] - light_pos[1],
-                                   (float)voxel[2] - light_pos[2]};
-                    max_distance = (int)((float)distance_traveled + sqrtf(dot3(dv, dv)));
-                }
-                float lv[3] = {light_pos[0] - hit_pos[0], light_pos[1] - hit_pos[1], light_pos[2] - hit_pos[2]};
-                normalize3(lv, rd);                               /* :670 */
-                if (rd[0] == 0.0f || rd[1] == 0.0f || rd[2] == 0.0f) {   /* :671-672 */
+                if (!light_from_strike(s, s->lights, &strike, voxel_color, color_accumulator, rd, voxel, vstep,
+                                       delta_t, it, &max_distance, 1)) {
                     flags &= ~ORC_FLAG_WRITTEN;
                     goto done_unwritten;
                 }
                 ctr->shadow_rays++;
                 flags |= ORC_FLAG_SHADOW_CAST;
-                for (int a = 0; a < 3; a++) {
-                    voxel[a] -= vstep[a] * face_mask[a];          /* :674 */
-                    vstep[a] = isign(rd[a]);                      /* :675 */
-                    delta_t[a] = fabsf(1.0f / rd[a]);             /* :677 */
-                    it[a] = delta_t[a] * (hit_pos[a] - floorf(hit_pos[a])) * (float)vstep[a];   /* :678 */
-                    it[a] += delta_t[a] * -(it[a] < 0.0f ? -1.0f : 0.0f);                       /* :679 */
-                }
             } else if (voxel_data == 6 && !shadow_ray) {          /* :682-704 */
                 int tx = (int)(tile_face_position[0] * (float)tiles_x) + (int)(3.0f * (float)tiles_x);
                 int ty = (int)(tile_face_position[1] * (float)tiles_y) + (int)(4.0f * (float)tiles_y);
@@ -604,6 +640,19 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
             }
         }
         distance_traveled++;                                      /* :714 */
+    }
+        /* multi-light extension: the shadow ray of light l ended (step cap :357, left the map :563-568 or
+         * blocked :707-710); reset to the first strike and run the light block for the next light, chaining
+         * the colour.  Never taken with one active light.                                                   */
+        if (!(shadow_ray && s->shadow_rays && light_index + 1 < nlights)) break;
+        light_index++;
+        if (!light_from_strike(s, s->lights + 10 * light_index, &strike, color_accumulator, color_accumulator, rd,
+                               voxel, vstep, delta_t, it, &max_distance, 1)) {
+            flags &= ~ORC_FLAG_WRITTEN;
+            goto done_unwritten;
+        }
+        ctr->shadow_rays++;
+        distance_traveled = strike.distance + 1;      /* as if the strike iteration had just finished (:714) */
     }
 
     {

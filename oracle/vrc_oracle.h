@@ -114,12 +114,14 @@ typedef struct {
     /* extensions; the defaults reproduce the reference */
     int32_t         max_distance;        /* ray_caster_kernel.cl:326 => 20 */
     int32_t         shadow_rays;         /* 1; 0 = shade the primary hit and stop */
+    int32_t         active_lights;       /* <= 1: light 0 only (the reference); n: the first n lights, each
+                                            from the first strike (see light_from_strike)       */
     float           cam_trig[4];         /* sin(dir.x) cos(dir.x) sin(dir.y) cos(dir.y) */
 } orc_scene;
 
 typedef struct {
     uint64_t primary_rays;   /* pixels passing the zero-component test (:293) */
-    uint64_t shadow_rays;    /* redirects toward light 0 (:670-679) */
+    uint64_t shadow_rays;    /* redirects toward a light (:670-679) */
     uint64_t n_desc;         /* canonical descriptor reads */
     uint64_t n_tex;          /* atlas texels fetched */
     uint64_t n_map;          /* dense-grid bytes fetched */

@@ -24,4 +24,5 @@ def render_with_oracle(g, **kw):
     return orc.raycast(width=int(g["width"]), height=int(g["height"]), cam_dir=g["cam_dir"], cam_pos=g["cam_pos"],
                        lights=g["lights"], atlas=g["atlas"], tile_dim=(16, 16), descriptors=g["descriptors"],
                        root_index=int(g["root_index"]), octree_dim=int(g["dim"]), using_octree=int(g["using_octree"]),
-                       grid=g["grid"], max_distance=int(g["max_distance"]), viewport=g["viewport"], trig=g["cam_trig"], **kw)
+                       grid=g["grid"], max_distance=int(g["max_distance"]), viewport=g["viewport"], trig=g["cam_trig"],
+                       active_lights=int(g.get("active_lights", 1)), **kw)

@@ -86,4 +86,20 @@ def random_sparse(dim=64, density=0.02, seed=11):
                 cam_dir=(2.0, 1.5708), lights=lights)
 
 
+def with_lights(s, n):
+    """The scene with n lights (multi-light extension): light 0 is the scene's own, the others sit
+    inside the map above the floor, outside the map, close to the floor and in a far corner."""
+    d = float(s["dim"])
+    extra = np.array([[0.30, 0.10, 0.05, 0.3, d * 0.5 + 0.3, d * 0.6 + 0.2, d * 0.7 + 0.1, 0, 0, -1],
+                      [0.05, 0.25, 0.10, 0.2, d * 1.5, d * 0.5 + 0.4, d * 1.2, 0, 0, -1],
+                      [0.05, 0.05, 0.30, 0.1, d * 0.2 + 0.6, d * 0.8 + 0.1, 4.3, 0, 0, -1],
+                      [0.20, 0.20, 0.20, 0.4, -3.5, -2.25, d * 0.9, 0, 0, -1],
+                      [0.10, 0.00, 0.10, 0.2, d - 1.5, d - 1.25, d - 0.75, 0, 0, -1],
+                      [0.00, 0.10, 0.10, 0.2, d * 0.35, d * 0.15, d * 0.5, 0, 0, -1],
+                      [0.15, 0.05, 0.00, 0.2, d * 0.65, d * 0.35, d * 0.25, 0, 0, -1]], dtype=np.float32)
+    out = dict(s)
+    out["lights"] = np.concatenate([np.asarray(s["lights"], dtype=np.float32).reshape(-1, 10)[:1], extra])[:n].copy()
+    return out
+
+
 ALL = [app_default, floor_pillars, mirror_wall, open_sky, axis_aligned, random_sparse]

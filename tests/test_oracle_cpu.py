@@ -250,6 +250,65 @@ def test_primary_only_extension(atlas):
     assert ctr["shadow_rays"] == 0 and ctr["primary_rays"] > 0
 
 
+# ---------------------------------------------------------------- 8f-1 multi-light extension
+@pytest.mark.parametrize("make", [scenes.floor_pillars, scenes.random_sparse, scenes.mirror_wall])
+def test_multi_light_off_by_default_and_reduces_to_reference(make, atlas):
+    """The reference binds light_count but shades with light 0 only (ray_caster_kernel.cl:264,660-670): with
+    active_lights = 1 further lights change nothing, and n active lights with one light supplied is that too."""
+    s1, s4 = make(), scenes.with_lights(make(), 4)
+    ref = _render(s1, 0, atlas)
+    for got in (_render(s4, 0, atlas), _render(s4, 0, atlas, active_lights=1), _render(s1, 0, atlas, active_lights=4)):
+        assert np.array_equal(ref[0].view(np.uint32), got[0].view(np.uint32)) and np.array_equal(ref[1], got[1])
+        assert ref[2] == got[2]
+
+
+@pytest.mark.parametrize("using_octree", [1, 0], ids=["array", "svo"])
+@pytest.mark.parametrize("make", [scenes.floor_pillars, scenes.random_sparse, scenes.open_sky, scenes.mirror_wall])
+def test_multi_light_is_the_shadow_block_restarted_per_light(make, using_octree, atlas):
+    """First-strike resetting (TODO src/main.cpp:33): the shadow ray toward light l starts from the stored primary
+    hit, so what happens to it -- blocked, left the map, step cap, final step count -- is what a single-light frame
+    with light l in slot 0 reports.  Checks the reset control flow without restating any colour arithmetic."""
+    n = 4
+    s = scenes.with_lights(make(), n)
+    img, hits, ctr = _render(s, using_octree, atlas, active_lights=n)
+    singles = []
+    for l in range(n):
+        one = dict(s)
+        one["lights"] = s["lights"][l:l + 1]
+        singles.append(_render(one, using_octree, atlas))
+    assert np.array_equal(hits[..., :5], singles[0][1][..., :5])                 # the primary hit is light-independent
+    F = [x[1][..., 5] for x in singles]
+    alive = np.ones(F[0].shape, dtype=bool)          # pixels whose chain reaches light l (an unwritten return ends it)
+    expect_flags = np.zeros_like(F[0])
+    expect_steps = np.zeros_like(F[0])
+    casts = 0
+    for l in range(n):
+        cast = alive & ((F[l] & 2) != 0)
+        if l == 0:
+            expect_flags, expect_steps = F[0].copy(), singles[0][1][..., 6].copy()
+            chain = (F[0] & 2) != 0                                              # a shadow ray was cast: more lights follow
+            alive = chain & ((F[0] & 1) != 0)
+        else:
+            expect_flags = np.where(alive, (expect_flags | F[l]) & (F[l] | ~np.int32(1)), expect_flags)
+            expect_steps = np.where(alive, singles[l][1][..., 6], expect_steps)
+            alive = alive & ((F[l] & 1) != 0)
+        casts += int(cast.sum())
+    assert np.array_equal(hits[..., 5], expect_flags)
+    assert np.array_equal(hits[..., 6], expect_steps)
+    assert ctr["shadow_rays"] == casts and ctr["n_tex"] == singles[0][2]["n_tex"]
+    if make is not scenes.mirror_wall:
+        assert casts > singles[0][2]["shadow_rays"] > 0
+
+
+def test_multi_light_primary_only_shades_with_every_light(atlas):
+    s = scenes.with_lights(scenes.floor_pillars(), 3)
+    one = _render(s, 0, atlas, shadow_rays=0)
+    three = _render(s, 0, atlas, shadow_rays=0, active_lights=3)
+    assert three[2]["shadow_rays"] == 0 and np.array_equal(one[1], three[1])
+    hit = one[1][..., 3] == 5
+    assert (three[0][hit][:, :3] > one[0][hit][:, :3]).all()                    # every light adds diffuse >= 0.1 * rgb
+
+
 def test_threads_do_not_change_the_frame(atlas):
     s = scenes.random_sparse()
     a = _render(s, 0, atlas, threads=1)

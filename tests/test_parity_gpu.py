@@ -22,13 +22,15 @@ RTOL = 1e-5  # BASELINE.json north_star tolerance for RGB floats
 
 
 def make_caster(octree, dim, using_octree, cam_dir, cam_pos, lights, atlas, w, h, max_distance, grid=None,
-                shadow_rays=1):
+                shadow_rays=1, light_count=None):
     c = vrc.CLCaster()
     assert c.init(0), "vrc_create failed: is this a GPU box?"
     assert c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim)          # Application.cpp:35
     assert c.add_to_settings_buffer("using_octree", "OCTENABLED", using_octree)  # Application.cpp:38-39
     assert c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", max_distance)
     assert c.add_to_settings_buffer("shadow_rays", "SHADOW_RAYS", shadow_rays)
+    if light_count is not None:                                                  # multi-light extension (8f-1)
+        assert c.add_to_settings_buffer("light_count", "LIGHT_COUNT", light_count)
     assert c.assign_octree(octree)
     if grid is not None:
         assert c.assign_map(grid, (dim, dim, dim))
@@ -81,7 +83,7 @@ def test_hip_reproduces_committed_vectors(path):
     dim, w, h = int(g["dim"]), int(g["width"]), int(g["height"])
     o = vrc.Octree(g["descriptors"], int(g["root_index"]), dim)
     c = make_caster(o, dim, int(g["using_octree"]), g["cam_dir"], g["cam_pos"], g["lights"], g["atlas"], w, h,
-                    int(g["max_distance"]), grid=g["grid"])
+                    int(g["max_distance"]), grid=g["grid"], light_count=int(g.get("active_lights", 1)))
     assert c.compute(), c.last_error()
     assert np.array_equal(c.read_hits(), g["hits"])
     assert np.array_equal(c.read_image().view(np.uint32), g["image"].view(np.uint32))
@@ -317,6 +319,27 @@ def test_baseline_configs_sampled_rows(depth, w, h):
         assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
 
 
+@pytest.mark.parametrize("w,h,n", [(3840, 2160, 2), (1920, 1080, 4)], ids=["C4-4K-2lights", "d12-1080p-4lights"])
+def test_multi_light_baseline_geometry_sampled_rows(w, h, n):
+    """BASELINE configs[3] geometry on one GPU (depth-12 SVO, 3840x2160, 2 lights) and configs[4]'s light count on
+    the headline scene: sampled rows bit-exact vs the oracle, shadow-ray counter = casts of every light."""
+    sc = _bench_scene(12)
+    dim = sc["dim"]
+    c = make_caster(sc["octree"], dim, 0, sc["cam_dir"], sc["cam_pos"], sc["lights"], sc["atlas"], w, h, 3 * dim,
+                    light_count=n)
+    assert c.compute(), c.last_error()
+    img, hits, ctr = c.read_image(), c.read_hits(), c.counters()
+    cast = (hits[..., 5] & 2) != 0
+    assert cast.sum() < ctr["shadow_rays"] <= n * cast.sum() and ctr["primary_rays"] == w * h
+    for y0 in range(29, h, 211):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=c._li,
+                                     atlas=sc["atlas"], tile_dim=(16, 16), descriptors=sc["octree"].descriptor_buffer,
+                                     root_index=sc["octree"].root_index, octree_dim=dim, using_octree=0,
+                                     max_distance=3 * dim, rows=(y0, y0 + 1), threads=8, active_lights=n)
+        assert np.array_equal(hits[y0], ohits[y0])
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+
+
 def test_depth13_scene_sampled_rows():
     """Beyond the headline: 8192^3 (depth 13), 84 M descriptors (674 MB), thousands of far pointers and page
     headers, 12 stack levels in LDS -- sampled rows bit-exact vs the oracle, counters consistent."""
@@ -390,20 +413,80 @@ def test_fuzz_random_scenes(seed, atlas):
     if rng.random() < 0.2:
         cam_pos = tuple(float(int(v)) for v in cam_pos)               # on integer coordinates
     cam_dir = (float(rng.random() * 3.0 + 0.1), float(rng.random() * 6.2))
-    lights = np.array([[0.01, 0.01, 0.01, 0.2, *(rng.random(3) * dim * 1.2), -1, -1, -1.5]], dtype=np.float32)
+    nl = int(rng.choice([1, 1, 2, 3, 8]))                                # multi-light extension on half the seeds
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, *(rng.random(3) * dim * 1.4 - 0.2 * dim), -1, -1, -1.5] for _ in range(nl)],
+                      dtype=np.float32)
+    if nl > 1 and rng.random() < 0.3:
+        lights[1, 4:7] = np.floor(lights[1, 4:7]) + 0.5                   # voxel centres: zero ray components (:671)
     w, h = int(rng.integers(9, 90)), int(rng.integers(9, 60))
     md = int(rng.choice([0, 1, 7, 20, 3 * dim]))
     o = vrc.Octree.Generate(g, dim, buffer_size=100000).attach_materials_from_grid(g)
     for using_octree, jump in ((1, False), (0, False), (0, True)):
-        c = make_caster(o, dim, using_octree, cam_dir, cam_pos, lights, atlas, w, h, md, grid=g)
+        c = make_caster(o, dim, using_octree, cam_dir, cam_pos, lights, atlas, w, h, md, grid=g, light_count=nl)
         if jump:
             assert c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 2)
         assert c.compute(), c.last_error()
         kw = dict(attachment_lookup=o.attachment_lookup, attachments=o.attachment_buffer) if not using_octree else {}
         oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas,
                                         tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
-                                        octree_dim=dim, using_octree=using_octree, grid=g, max_distance=md, **kw)
+                                        octree_dim=dim, using_octree=using_octree, grid=g, max_distance=md,
+                                        active_lights=nl, **kw)
         assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+
+
+@pytest.mark.parametrize("mode", ["array", "svo", "svo_jump", "svo_primary_only"])
+@pytest.mark.parametrize("n", [2, 4, 8])
+@pytest.mark.parametrize("make", [scenes.floor_pillars, scenes.random_sparse, scenes.open_sky, scenes.mirror_wall,
+                                  scenes.app_default], ids=lambda f: f.__name__)
+def test_multi_light_equals_oracle(make, n, mode, atlas):
+    """Multi-light extension (setting light_count): every finished shadow ray goes back to the first
+    strike for the next light; array kernel, SVO kernel (lane mode kRelight), with jumps and without shadow rays."""
+    s = scenes.with_lights(make(), n)
+    dim, w, h = s["dim"], 160, 120
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+    md = 20 if dim <= 16 else 3 * dim
+    using_octree = 1 if mode == "array" else 0
+    sr = 0 if mode == "svo_primary_only" else 1
+    c = make_caster(o, dim, using_octree, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md, grid=s["grid"],
+                    shadow_rays=sr, light_count=n)
+    if mode == "svo_jump":
+        assert c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 2)
+    assert c.compute(), c.last_error()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=c._li, atlas=atlas,
+                                    tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                    octree_dim=dim, using_octree=using_octree, grid=s["grid"], max_distance=md,
+                                    shadow_rays=sr, active_lights=n)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+    if sr and make is not scenes.mirror_wall and make is not scenes.app_default:
+        assert octr["shadow_rays"] > octr["primary_rays"] * 0.5
+
+
+def test_multi_light_is_opt_in_and_follows_the_live_count(atlas):
+    """Default: the reference's behaviour -- light_count is bound but only light 0 shades (ray_caster_kernel.cl:264).
+    With the setting, the lights used are min(setting, *light_count), re-read on every compute."""
+    s = scenes.with_lights(scenes.floor_pillars(), 4)
+    dim, w, h, md = s["dim"], 96, 64, 96
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+
+    def oracle(n):
+        return orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=c._li, atlas=atlas,
+                           tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index, octree_dim=dim,
+                           using_octree=0, max_distance=md, active_lights=n)
+
+    c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+    assert c.compute()
+    assert_same(c.read_image(), c.read_hits(), c.counters(), *oracle(1))
+    assert c.add_to_settings_buffer("light_count", "LIGHT_COUNT", 8)
+    count = np.array([3], dtype=np.int32)
+    assert c.assign_lights(c._li, count) and c.validate(), c.last_error()
+    assert c.compute(), c.last_error()
+    assert_same(c.read_image(), c.read_hits(), c.counters(), *oracle(3))
+    count[0] = 2                                      # live buffer: no re-assign
+    assert c.compute()
+    assert_same(c.read_image(), c.read_hits(), c.counters(), *oracle(2))
+    count[0] = 0                                      # never fewer than light 0
+    assert c.compute()
+    assert_same(c.read_image(), c.read_hits(), c.counters(), *oracle(1))
 
 
 def test_bench_two_rank_rehearsal():

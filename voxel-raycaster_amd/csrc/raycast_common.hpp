@@ -70,6 +70,12 @@ struct Ray {
     int flags;
     int hit_vx, hit_vy, hit_vz, hit_mat, hit_face;
     unsigned c_tex, c_shadow;
+    // the first strike (primary hit): what the light block needs to run again for a further light
+    int kvx, kvy, kvz;                   // the solid voxel
+    float kfx, kfy, kfz;                 // face_position
+    int kmx, kmy, kmz;                   // face_mask * voxel_step of the primary ray
+    int kdist;                           // distance_traveled at the strike
+    int light_index;
 };
 
 // :276-323 + the frame-constant bias of :342-354.  Returns false for the
@@ -81,6 +87,7 @@ __device__ __forceinline__ bool ray_setup(Ray &r, const RaycastParams &p, long p
     r.bounce_count = 0;
     r.written = false;
     r.c_tex = r.c_shadow = 0;
+    r.light_index = 0;
 
     const float4 pm = reinterpret_cast<const float4 *>(p.viewport)[pix];
     {
@@ -127,8 +134,54 @@ __device__ __forceinline__ void oob_exit(Ray &r) {
     r.flags |= kFlagOob;
 }
 
+// :677-679 / :700-702: delta_t and intersection_t of a ray restarted at hit_pos (ray_dir, voxel_step already set)
+__device__ __forceinline__ void restart_from(Ray &r, Vec3 hit_pos) {
+    r.dtx = fabsf(1.0f / r.rdx); r.dty = fabsf(1.0f / r.rdy); r.dtz = fabsf(1.0f / r.rdz);
+    r.itx = r.dtx * (hit_pos.x - floorf(hit_pos.x)) * (float)r.sx;
+    r.ity = r.dty * (hit_pos.y - floorf(hit_pos.y)) * (float)r.sy;
+    r.itz = r.dtz * (hit_pos.z - floorf(hit_pos.z)) * (float)r.sz;
+    r.itx += r.dtx * -(r.itx < 0.0f ? -1.0f : 0.0f);
+    r.ity += r.dty * -(r.ity < 0.0f ? -1.0f : 0.0f);
+    r.itz += r.dtz * -(r.itz < 0.0f ? -1.0f : 0.0f);
+}
+
+// The light part of the hit block (:657-679) for light l, run from the FIRST STRIKE stored in r.k*:
+// view_light, max_distance, redirect toward the light.  For l = 0 this is the reference's code at its place; the
+// multi-light extension (TODO src/main.cpp:33 "first-strike resetting") runs it again for each
+// further light, chaining the colour.  Returns false for the early return of :671-672 (pixel left unwritten).
+__device__ __forceinline__ bool light_from_strike(Ray &r, const RaycastParams &p, int l, bool cast) {
+    const Vec3 light_pos{p.lights[l][4], p.lights[l][5], p.lights[l][6]};
+    const Vec3 hit_pos{(float)r.kvx + r.kfx, (float)r.kvy + r.kfy, (float)r.kvz + r.kfz};
+    view_light(r.color_accumulator, l == 0 ? r.voxel_color : r.color_accumulator,
+               Vec3{hit_pos.x - light_pos.x, hit_pos.y - light_pos.y, hit_pos.z - light_pos.z}, p.lights[l],
+               Vec3{hit_pos.x - p.cam_pos[0], hit_pos.y - p.cam_pos[1], hit_pos.z - p.cam_pos[2]}, r.kmx, r.kmy, r.kmz);
+    if (!cast) return true;
+    {
+        const float ddx = (float)r.kvx - light_pos.x, ddy = (float)r.kvy - light_pos.y, ddz = (float)r.kvz - light_pos.z;
+        r.max_distance = (int)((float)r.kdist + sqrtf(dot3(ddx, ddy, ddz, ddx, ddy, ddz)));       // :667
+    }
+    const Vec3 nd = normalize3(Vec3{light_pos.x - hit_pos.x, light_pos.y - hit_pos.y, light_pos.z - hit_pos.z});
+    r.rdx = nd.x; r.rdy = nd.y; r.rdz = nd.z;                                 // :670
+    if (r.rdx == 0.0f || r.rdy == 0.0f || r.rdz == 0.0f) { r.written = false; return false; }   // :671-672
+    r.c_shadow++;
+    r.flags |= kFlagShadowCast;
+    r.vx = r.kvx - r.kmx; r.vy = r.kvy - r.kmy; r.vz = r.kvz - r.kmz;         // :674 voxel -= voxel_step * face_mask
+    r.sx = isign(r.rdx); r.sy = isign(r.rdy); r.sz = isign(r.rdz);            // :675
+    return true;                                                              // the caller restarts: :677-679
+}
+__device__ __forceinline__ Vec3 strike_pos(const Ray &r) {
+    return Vec3{(float)r.kvx + r.kfx, (float)r.kvy + r.kfy, (float)r.kvz + r.kfz};
+}
+
+// multi-light extension: the shadow ray toward light r.light_index has ended (step cap :357, left the map
+// :563-568, or blocked :707-710) and another light is waiting
+__device__ __forceinline__ bool more_lights(const Ray &r, const RaycastParams &p) {
+    return r.shadow_ray && r.written && p.shadow_rays && r.light_index + 1 < p.light_count;
+}
+
 // :575-711 for voxel_data in {5, 6}.  Returns true when the loop breaks / the
 // kernel returns, false when the (redirected) ray keeps stepping.
+template <bool kMulti>
 __device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastParams &p) {
     float fpx = 0.f, fpy = 0.f, fpz = 0.f, tfx = 0.f, tfy = 0.f;
     float sgx = 1.0f, sgy = 1.0f, sgz = 1.0f;
@@ -187,27 +240,21 @@ __device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastP
     r.voxel_color[1] += ((float)t8.y / 255.0f) / div;
     r.voxel_color[2] += ((float)t8.z / 255.0f) / div;
 
-    const Vec3 light_pos{p.light_pos[0], p.light_pos[1], p.light_pos[2]};
     const Vec3 hit_pos{(float)r.vx + fpx, (float)r.vy + fpy, (float)r.vz + fpz};
     if (!mirror) {                                                            // :649-679
         r.shadow_ray = true;
-        view_light(r.color_accumulator, r.voxel_color,
-                   Vec3{hit_pos.x - light_pos.x, hit_pos.y - light_pos.y, hit_pos.z - light_pos.z}, p.light_rgbi,
-                   Vec3{hit_pos.x - p.cam_pos[0], hit_pos.y - p.cam_pos[1], hit_pos.z - p.cam_pos[2]},
-                   r.fmx * r.sx, r.fmy * r.sy, r.fmz * r.sz);
+        r.kvx = r.vx; r.kvy = r.vy; r.kvz = r.vz;
+        r.kfx = fpx; r.kfy = fpy; r.kfz = fpz;
+        r.kmx = r.fmx * r.sx; r.kmy = r.fmy * r.sy; r.kmz = r.fmz * r.sz;
+        r.kdist = r.distance_traveled;
         r.fog_distance = (float)r.distance_traveled;                          // :666
-        if (!p.shadow_rays) return true;                                      // extension: primary rays only
-        {
-            const float ddx = (float)r.vx - light_pos.x, ddy = (float)r.vy - light_pos.y, ddz = (float)r.vz - light_pos.z;
-            r.max_distance = (int)((float)r.distance_traveled + sqrtf(dot3(ddx, ddy, ddz, ddx, ddy, ddz)));   // :667
+        const bool cast = p.shadow_rays != 0;
+        if (!light_from_strike(r, p, 0, cast)) return true;
+        if (!cast) {                                                          // extension: primary rays only;
+            if (kMulti)                                                       // every active light shades
+                for (int l = 1; l < p.light_count; l++) light_from_strike(r, p, l, false);
+            return true;
         }
-        const Vec3 nd = normalize3(Vec3{light_pos.x - hit_pos.x, light_pos.y - hit_pos.y, light_pos.z - hit_pos.z});
-        r.rdx = nd.x; r.rdy = nd.y; r.rdz = nd.z;                             // :670
-        if (r.rdx == 0.0f || r.rdy == 0.0f || r.rdz == 0.0f) { r.written = false; return true; }   // :671-672
-        r.c_shadow = 1;
-        r.flags |= kFlagShadowCast;
-        r.vx -= r.sx * r.fmx; r.vy -= r.sy * r.fmy; r.vz -= r.sz * r.fmz;     // :674
-        r.sx = isign(r.rdx); r.sy = isign(r.rdy); r.sz = isign(r.rdz);        // :675
     } else {                                                                  // :682-704
         r.rdx *= sgx; r.rdy *= sgy; r.rdz *= sgz;                             // :693
         if (r.rdx == 0.0f || r.rdy == 0.0f || r.rdz == 0.0f) { r.written = false; return true; }
@@ -218,13 +265,7 @@ __device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastP
         r.sz = (-1 * (r.rdz > 0.0f ? -1 : 0)) - (r.rdz < 0.0f ? -1 : 0);
         r.bounce_count += 1;
     }
-    r.dtx = fabsf(1.0f / r.rdx); r.dty = fabsf(1.0f / r.rdy); r.dtz = fabsf(1.0f / r.rdz);   // :677 / :700
-    r.itx = r.dtx * (hit_pos.x - floorf(hit_pos.x)) * (float)r.sx;                            // :678 / :701
-    r.ity = r.dty * (hit_pos.y - floorf(hit_pos.y)) * (float)r.sy;
-    r.itz = r.dtz * (hit_pos.z - floorf(hit_pos.z)) * (float)r.sz;
-    r.itx += r.dtx * -(r.itx < 0.0f ? -1.0f : 0.0f);                                          // :679 / :702
-    r.ity += r.dty * -(r.ity < 0.0f ? -1.0f : 0.0f);
-    r.itz += r.dtz * -(r.itz < 0.0f ? -1.0f : 0.0f);
+    restart_from(r, hit_pos);                                                 // :677-679 / :700-702
     return false;
 }
 

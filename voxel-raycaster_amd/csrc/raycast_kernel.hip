@@ -66,6 +66,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
         } else {
             c_primary = 1;
             c_desc = (unsigned)p.frame[3];                // the reference's per-pixel get_oct_vox (:342)
+            for (;;) {
             while (r.distance_traveled < r.max_distance && r.bounce_count < 2) {          // :357
                 c_steps++;
                 r.fmx = r.itx <= min_cl(r.ity, r.itz);                                      // :558
@@ -81,8 +82,15 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
                     p.map[(long)r.vx + (long)p.map_dim[0] * ((long)r.vy + (long)p.map_dim[2] * r.vz)];   // :569
                 c_map++;
                 if (voxel_data == 5 || voxel_data == 6)                                     // :575
-                    if (hit_block(r, voxel_data, p)) break;
+                    if (hit_block<true>(r, voxel_data, p)) break;
                 r.distance_traveled++;                                                      // :714
+            }
+                // multi-light extension: back to the first strike for the next light (never with one light)
+                if (!more_lights(r, p)) break;
+                r.light_index++;
+                if (!light_from_strike(r, p, r.light_index, true)) break;
+                restart_from(r, strike_pos(r));
+                r.distance_traveled = r.kdist + 1;        // as if the strike iteration had just finished (:714)
             }
             if (!r.written) c_unwritten = 1;
             c_tex = r.c_tex; c_shadow = r.c_shadow;
@@ -96,10 +104,12 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
 // ---------------------------------------------------------------------------
 // SVO branch
 // ---------------------------------------------------------------------------
-enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3 };
+enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3, kRelight = 4 };
 
 // kJump: also use the closed-form multi-iteration jumps of exact_jump.hpp (opt-in, setting jump_min_run)
-template <bool kJump>
+// kMulti: multi-light extension (setting light_count > 1): a finished shadow ray parks the lane in kRelight and
+//         the shade phase restarts it from the first strike toward the next light
+template <bool kJump, bool kMulti>
 __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const RaycastParams p) {
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
     __shared__ unsigned long long block_ctr[kCtrCount];
@@ -115,6 +125,9 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
     Ray r;
     unsigned c_primary = 0, c_desc = 0, c_unwritten = 0, broke = 0;
     int mode = kDone, mat = 5;
+    int steps_base = 0;                                   // iterations of the segments before the last reset (kMulti)
+    // a ray segment ended (:357 guard, :563-568, :707-710)
+    auto ended = [&]() -> int { return (kMulti && more_lights(r, p)) ? kRelight : kDone; };
 
     // stepping state while inside a known-empty node: countdown of steps to the
     // node face per axis, voxel_a = base_a - s_a * n_a
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                 VRC_STAT(w_jumps, 1);
                 if (jr.capped) {                          // :357 the step cap ends the loop inside the stretch
                     r.distance_traveled = r.max_distance;
-                    mode = kDone;
+                    mode = ended();
                 } else {
                     nx = (float)inx; ny = (float)iny; nz = (float)inz;
                     if (jr.left_node) {
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                         mode = kEvent;
                     } else {                              // stopped at a binade boundary: try once more
                         r.distance_traveled += jr.iterations;
-                        if (r.distance_traveled >= r.max_distance) mode = kDone;
+                        if (r.distance_traveled >= r.max_distance) mode = ended();
                     }
                 }
             }
@@ -297,12 +310,12 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                 r.distance_traveled += it - 1;            // the leaving iteration's :714 comes after the lookup
             } else {
                 r.distance_traveled += it;                // :714
-                if (it == true_limit) mode = kDone;       // :357
+                if (it == true_limit) mode = ended();     // :357
             }
         }
         const unsigned long long ev = __ballot(mode == kEvent);
         const unsigned long long st = __ballot(mode == kStep);
-        unsigned long long sh = __ballot(mode == kShade);
+        unsigned long long sh = __ballot(mode == kShade || (kMulti && mode == kRelight));
         if ((ev | st | sh) == 0ULL) break;
 
         // ---- phase 3: node events
@@ -316,13 +329,13 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                 if (r.vx >= p.map_dim[0] || r.vy >= p.map_dim[1] || r.vz >= p.map_dim[2] || r.vx < 0 || r.vy < 0 || r.vz < 0) {
                     oob_exit(r);                          // :563-568
                     broke = 1;
-                    mode = kDone;
+                    mode = ended();
                 } else {
                     const int b = locate(r.vx, r.vy, r.vz);
                     if (b >= 0) {
                         enter_node(b);
                         r.distance_traveled++;            // :714
-                        mode = (r.distance_traveled < r.max_distance) ? kStep : kDone;   // :357
+                        mode = (r.distance_traveled < r.max_distance) ? kStep : ended();   // :357
                     } else {
                         mat = solid_material(r.vx, r.vy, r.vz);
                         if (mat == 5 || mat == 6) {       // :575
@@ -330,27 +343,40 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                         } else {                          // any other material is passed through
                             enter_single();
                             r.distance_traveled++;        // :714
-                            mode = (r.distance_traveled < r.max_distance) ? kStep : kDone;   // :357
+                            mode = (r.distance_traveled < r.max_distance) ? kStep : ended();   // :357
                         }
                     }
                 }
             }
-            sh = __ballot(mode == kShade);
+            sh = __ballot(mode == kShade || (kMulti && mode == kRelight));
         }
 
         // ---- phase 4: hit block (:575-711): expensive and needed ~twice per pixel, so it runs only when
         // many lanes wait for it or nothing cheaper is left to do
         if (sh != 0ULL && (__ballot(mode == kStep) == 0ULL || __popcll(sh) >= shade_threshold)) {
             VRC_STAT(w_sh_passes, 1); VRC_STAT(w_sh_lanes, __popcll(sh));
-            if (mode == kShade) {
-                if (hit_block(r, mat, p)) {
+            if (kMulti && mode == kRelight) {             // back to the first strike for the next light
+                r.light_index++;
+                if (!light_from_strike(r, p, r.light_index, true)) {
+                    mode = kDone;                         // :671-672, pixel left unwritten
+                } else {
+                    restart_from(r, strike_pos(r));
+                    steps_base += r.distance_traveled + (int)broke - (r.kdist + 1);
+                    broke = 0;
+                    enter_single();
+                    if (kJump) jump_cache_reset(jcache);
+                    r.distance_traveled = r.kdist + 1;    // as if the strike iteration had just finished (:714)
+                    mode = (r.distance_traveled < r.max_distance) ? kStep : ended();
+                }
+            } else if (mode == kShade) {
+                if (hit_block<kMulti>(r, mat, p)) {
                     broke = 1;
-                    mode = kDone;
+                    mode = ended();
                 } else {
                     enter_single();
                     if (kJump) jump_cache_reset(jcache);  // delta_t changed with the redirect
                     r.distance_traveled++;                // :714
-                    mode = (r.distance_traveled < r.max_distance && r.bounce_count < 2) ? kStep : kDone;   // :357
+                    mode = (r.distance_traveled < r.max_distance && r.bounce_count < 2) ? kStep : ended();   // :357
                 }
             }
         }
@@ -359,7 +385,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
     unsigned c_steps = 0, c_tex = 0, c_shadow = 0;
     if (in_image) {
         if (c_primary) {
-            c_steps = (unsigned)r.distance_traveled + broke;
+            c_steps = (unsigned)(steps_base + r.distance_traveled) + broke;
             c_tex = r.c_tex; c_shadow = r.c_shadow;
             if (!r.written) c_unwritten = 1;
         }
@@ -432,10 +458,15 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
     if (p.svo) {
         const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
         const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t) + (size_t)p.lds_pad_bytes;
-        if (p.jump_min_run < (1 << 24))
-            hipLaunchKernelGGL(raycast_svo_kernel<true>, dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+        const bool jump = p.jump_min_run < (1 << 24), multi = p.light_count > 1;
+        if (jump && multi)
+            hipLaunchKernelGGL((raycast_svo_kernel<true, true>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+        else if (jump)
+            hipLaunchKernelGGL((raycast_svo_kernel<true, false>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+        else if (multi)
+            hipLaunchKernelGGL((raycast_svo_kernel<false, true>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
         else
-            hipLaunchKernelGGL(raycast_svo_kernel<false>, dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+            hipLaunchKernelGGL((raycast_svo_kernel<false, false>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
     } else {
         hipLaunchKernelGGL(raycast_array_kernel, dim3(nblocks), dim3(kBlockThreads), 0, stream, p);
     }

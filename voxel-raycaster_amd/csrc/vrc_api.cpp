@@ -394,8 +394,14 @@ int vrc_compute_async(vrc_caster *h) {
     for (int a = 0; a < 3; a++) p.cam_pos[a] = h->cam_pos[a];
     p.trig[0] = sinf(h->cam_dir[0]); p.trig[1] = cosf(h->cam_dir[0]);
     p.trig[2] = sinf(h->cam_dir[1]); p.trig[3] = cosf(h->cam_dir[1]);
-    for (int c = 0; c < 4; c++) p.light_rgbi[c] = h->lights[c];
-    for (int a = 0; a < 3; a++) p.light_pos[a] = h->lights[4 + a];
+    // the reference binds light_count but shades with light 0 only (ray_caster_kernel.cl:264,660-670); setting
+    // "light_count" (default 1) switches on the multi-light extension for the first n packed lights
+    p.light_count = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(setting_or(h, "light_count", 1), *h->light_count),
+                                                                    vrc::kMaxLights));
+    for (int l = 0; l < p.light_count; l++) {
+        for (int k = 0; k < 7; k++) p.lights[l][k] = h->lights[10 * l + k];
+        p.lights[l][7] = 0.0f;
+    }
     p.max_distance = (int32_t)setting_or(h, "max_distance", 20);
     p.shadow_rays = (int32_t)setting_or(h, "shadow_rays", 1);
     // wave scheduling knobs of the SVO kernel; they never change results

@@ -12,6 +12,7 @@ constexpr int kTileW = 8;             // one wavefront = one 8x8 pixel tile
 constexpr int kTileH = 8;
 constexpr int kTilesPerBlock = 4;     // 256-thread block = 4 horizontally adjacent tiles (32x8 px)
 constexpr int kBlockThreads = 64 * kTilesPerBlock;
+constexpr int kMaxLights = 8;         // light slots (include/LightController.h:95)
 constexpr int kMaxLevels = 24;        // descriptor levels the LDS stack can hold (dim <= 2^24)
 
 // hit-record flag bits (include/vrc.h VRC_HIT_FLAG_*)
@@ -48,9 +49,10 @@ struct RaycastParams {
     // arg 4-5: camera (trig evaluated once on the host: SURVEY D2)
     float cam_pos[3];
     float trig[4];                    // sin(dir.x) cos(dir.x) sin(dir.y) cos(dir.y)
-    // arg 6: light 0
-    float light_rgbi[4];
-    float light_pos[3];
+    // arg 6/7: lights[l] = rgbi[4], position[3], pad.  light_count = lights the kernel shades with: 1 (light 0
+    // only) is the reference; more is the multi-light extension (setting "light_count")
+    float lights[kMaxLights][8];
+    int32_t light_count;
     // frame constants written by frame_setup_kernel: {bias[3], reads} -- the
     // pixel-independent get_oct_vox(camera voxel) of ray_caster_kernel.cl:342-354
     int32_t *frame;
