@@ -108,7 +108,12 @@ int vrc_assign_camera(vrc_caster *h, const float *direction2, const float *posit
 int vrc_release_camera(vrc_caster *h);
 /* CLCaster::assign_lights (CLCaster.cpp:313-328): packed = 10 floats per light
  * {rgbi[4], position[3], direction[3]} (include/LightController.h:63-73), 8
- * reserved slots in the reference; light_count points at the live count.     */
+ * reserved slots in the reference; light_count points at the live count.
+ * The reference kernel shades with light 0 only whatever *light_count holds
+ * (ray_caster_kernel.cl:264,660-670) and so does this library by default.
+ * Extension: setting "light_count" = n > 1 shades with the first
+ * min(n, *light_count, 8) lights, each shadow ray restarted from the primary
+ * hit ("first-strike resetting", TODO src/main.cpp:33).  */
 int vrc_assign_lights(vrc_caster *h, const float *packed, const int32_t *light_count);
 
 /* ---- settings buffer --------------------------------------------------- */
@@ -121,7 +126,7 @@ int vrc_assign_lights(vrc_caster *h, const float *packed, const int32_t *light_c
  *   using_octree       (OCTENABLED)        0 => occupancy from the SVO, != 0 => dense map
  *   octree_root_index  (OCTREE_ROOT_INDEX) set by vrc_assign_octree
  * extensions (defaults reproduce the reference):
- *   max_distance (20)  shadow_rays (1)                                        */
+ *   max_distance (20)  shadow_rays (1)  light_count (1, see vrc_assign_lights) */
 int vrc_setting_add(vrc_caster *h, const char *name, const char *define, int64_t value);
 /* CLCaster::overwrite_setting (CLCaster.cpp:1087-1109) */
 int vrc_setting_set(vrc_caster *h, const char *name, int64_t value);
