@@ -155,6 +155,9 @@ EDGE_CASES = [
     ("tiny_map_dim2", 2, (0.6, 0.4, 1.3), (2.2, 0.9), 8),
     ("tiny_map_dim4", 4, (1.6, 0.4, 3.3), (2.2, 0.9), 12),
     ("camera_inside_solid", 32, (16.5, 16.5, 1.5), (1.2, 2.0), 96),
+    # t values below 2^-100: the step loop's arithmetic face mask must hand over to the compare/select loop
+    ("camera_at_tiny_offsets", 16, (1e-36, 3e-37, 9.0 + 2.0 ** -20), (2.0, 1.5708), 40),
+    ("camera_at_denormal_offsets", 16, (1e-41, 5e-42, 1e-39), (0.9, 0.7), 40),
 ]
 
 
@@ -175,6 +178,24 @@ def test_edge_cases(case, using_octree, atlas):
                                     tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
                                     octree_dim=dim, using_octree=using_octree, grid=g, max_distance=md)
     assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+
+
+@pytest.mark.parametrize("make", [scenes.floor_pillars, scenes.random_sparse, scenes.app_default],
+                         ids=["floor_pillars", "random_sparse", "app_default"])
+def test_step_loop_variants_agree(make, atlas):
+    """Setting arith_mask picks how the SVO step loop forms face_mask (v_cmp/v_cndmask or subtract + clamped fma):
+    a speed knob, same frame either way."""
+    s = make()
+    dim, w, h = s["dim"], 160, 120
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+    md = 20 if dim <= 16 else 3 * dim
+    frames = []
+    for v in (0, 1):
+        c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+        assert c.add_to_settings_buffer("arith_mask", "ARITH_MASK", v) and c.compute(), c.last_error()
+        frames.append((c.read_image(), c.read_hits(), c.counters()))
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
+    assert np.array_equal(frames[0][1], frames[1][1]) and frames[0][2] == frames[1][2]
 
 
 def test_non_cubic_dense_map(atlas):

@@ -104,6 +104,14 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
 // ---------------------------------------------------------------------------
 // SVO branch
 // ---------------------------------------------------------------------------
+// 1.0 when d == 0, 0.0 when d >= 2^-127 (one full-rate VALU op: v_fma_f32 with the clamp modifier)
+__device__ __forceinline__ float unit_if_zero(float d) {
+    float f;
+    asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(f) : "v"(d), "s"(-0x1p127f));
+    return f;
+}
+__device__ __forceinline__ bool t_safe(float t) { return t == 0.0f || t >= 0x1p-100f; }
+
 enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3, kRelight = 4 };
 
 // kJump: also use the closed-form multi-iteration jumps of exact_jump.hpp (opt-in, setting jump_min_run)
@@ -125,6 +133,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
     Ray r;
     unsigned c_primary = 0, c_desc = 0, c_unwritten = 0, broke = 0;
     int mode = kDone, mat = 5;
+    bool t_unsafe = true;                                 // see arith_mask below
     int steps_base = 0;                                   // iterations of the segments before the last reset (kMulti)
     // a ray segment ended (:357 guard, :563-568, :707-710)
     auto ended = [&]() -> int { return (kMulti && more_lights(r, p)) ? kRelight : kDone; };
@@ -282,6 +291,12 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
             }
         }
 
+        // the arithmetic face_mask of the step loop needs every t to be 0 or >= 2^-100.  t only grows by
+        // delta_t >= 1/2 per step, so once a lane is safe it stays safe until its ray is restarted (t_unsafe is set
+        // again there); a wave with an unsafe stepping lane takes the compare/select loop for this burst.
+        if (t_unsafe) t_unsafe = !(t_safe(r.itx) && t_safe(r.ity) && t_safe(r.itz));
+        const bool arith_mask = p.arith_mask != 0 && __ballot(mode == kStep && t_unsafe) == 0ULL;
+
         // ---- phase 2: ordinary steps (:357-560) for lanes still inside their node.  A lane that is waiting
         // to jump only takes two steps (enough to settle its progressions); the others run to their node face.
         if (mode == kStep) {
@@ -290,19 +305,39 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
             const int it_limit = true_limit < cap ? true_limit : cap;
             float left = (float)it_limit;                  // per-lane countdown (exact: < 2^24)
             bool go;
-            do {
-                const float m = fminf(fminf(r.itx, r.ity), r.itz);
-                fxf = r.itx <= m ? 1.0f : 0.0f;           // :558 (ties step several axes)
-                fyf = r.ity <= m ? 1.0f : 0.0f;
-                fzf = r.itz <= m ? 1.0f : 0.0f;
-                r.itx = __builtin_fmaf(r.dtx, fxf, r.itx);   // :559, exact: dt * {0,1} has no rounding
-                r.ity = __builtin_fmaf(r.dty, fyf, r.ity);
-                r.itz = __builtin_fmaf(r.dtz, fzf, r.itz);
-                nx -= fxf; ny -= fyf; nz -= fzf;          // :560 as countdowns to the node face
-                left -= 1.0f;
-                go = fminf(fminf(fminf(nx, ny), nz), left) != 0.0f;
-                VRC_STAT(w_iters, 1);
-            } while (go);
+            if (arith_mask) {
+                // face_mask by arithmetic instead of v_cmp + v_cndmask (full-rate VALU ops on gfx950):
+                // d = t - min >= 0 is 0 exactly when t == min (IEEE subtraction with denormals never rounds a
+                // non-zero difference to 0), and clamp(1 - d * 2^127) is 1 for d == 0 and 0 for d >= 2^-127,
+                // which holds for every non-zero d because all t are 0 or >= 2^-100 here (t_safe below).
+                do {
+                    const float m = fminf(fminf(r.itx, r.ity), r.itz);
+                    fxf = unit_if_zero(r.itx - m);        // :558 (ties step several axes)
+                    fyf = unit_if_zero(r.ity - m);
+                    fzf = unit_if_zero(r.itz - m);
+                    r.itx = __builtin_fmaf(r.dtx, fxf, r.itx);   // :559, exact: dt * {0,1} has no rounding
+                    r.ity = __builtin_fmaf(r.dty, fyf, r.ity);
+                    r.itz = __builtin_fmaf(r.dtz, fzf, r.itz);
+                    nx -= fxf; ny -= fyf; nz -= fzf;      // :560 as countdowns to the node face
+                    left -= 1.0f;
+                    go = fminf(fminf(fminf(nx, ny), nz), left) != 0.0f;
+                    VRC_STAT(w_iters, 1);
+                } while (go);
+            } else {
+                do {
+                    const float m = fminf(fminf(r.itx, r.ity), r.itz);
+                    fxf = r.itx <= m ? 1.0f : 0.0f;       // :558 (ties step several axes)
+                    fyf = r.ity <= m ? 1.0f : 0.0f;
+                    fzf = r.itz <= m ? 1.0f : 0.0f;
+                    r.itx = __builtin_fmaf(r.dtx, fxf, r.itx);   // :559, exact: dt * {0,1} has no rounding
+                    r.ity = __builtin_fmaf(r.dty, fyf, r.ity);
+                    r.itz = __builtin_fmaf(r.dtz, fzf, r.itz);
+                    nx -= fxf; ny -= fyf; nz -= fzf;      // :560 as countdowns to the node face
+                    left -= 1.0f;
+                    go = fminf(fminf(fminf(nx, ny), nz), left) != 0.0f;
+                    VRC_STAT(w_iters, 1);
+                } while (go);
+            }
             const int it = it_limit - (int)left;          // iterations this lane executed in the burst
             VRC_STAT(w_bursts, 1);
             if (fminf(fminf(nx, ny), nz) == 0.0f) {       // left the node: bounds test + lookup pending
@@ -361,6 +396,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                     mode = kDone;                         // :671-672, pixel left unwritten
                 } else {
                     restart_from(r, strike_pos(r));
+                    t_unsafe = true;
                     steps_base += r.distance_traveled + (int)broke - (r.kdist + 1);
                     broke = 0;
                     enter_single();
@@ -374,6 +410,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                     mode = ended();
                 } else {
                     enter_single();
+                    t_unsafe = true;
                     if (kJump) jump_cache_reset(jcache);  // delta_t changed with the redirect
                     r.distance_traveled++;                // :714
                     mode = (r.distance_traveled < r.max_distance && r.bounce_count < 2) ? kStep : ended();   // :357

@@ -53,6 +53,7 @@ struct RaycastParams {
     // only) is the reference; more is the multi-light extension (setting "light_count")
     float lights[kMaxLights][8];
     int32_t light_count;
+    int32_t arith_mask;
     // frame constants written by frame_setup_kernel: {bias[3], reads} -- the
     // pixel-independent get_oct_vox(camera voxel) of ray_caster_kernel.cl:342-354
     int32_t *frame;
