@@ -11,6 +11,9 @@ def main():
     depth = int(os.environ.get("DEPTH", "12"))
     sc = bench.build_scene(depth)
     c = bench.make_caster(sc, 1920, 1080, 0)
+    for kv in filter(None, os.environ.get("EXTRA", "").split(",")):      # fixed settings: EXTRA="a=1,b=2"
+        k, v = kv.split("=")
+        c.add_to_settings_buffer(k, k.upper(), int(v))
     c.add_to_settings_buffer(name, name.upper(), values[0])
     for v in values:
         c.overwrite_setting(name, v)

@@ -110,6 +110,18 @@ __device__ __forceinline__ float unit_if_zero(float d) {
     asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(f) : "v"(d), "s"(-0x1p127f));
     return f;
 }
+// as unit_if_zero, but 0.0 for every d >= 0 when alive == 0.0 (alive is 1.0 or 0.0)
+__device__ __forceinline__ float alive_if_zero(float d, float alive) {
+    float f;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(f) : "v"(d), "s"(-0x1p127f), "v"(alive));
+    return f;
+}
+// min(a * b, 1) for a, b >= 0
+__device__ __forceinline__ float mul_clamped(float a, float b) {
+    float f;
+    asm("v_mul_f32 %0, %1, %2 clamp" : "=v"(f) : "v"(a), "v"(b));
+    return f;
+}
 __device__ __forceinline__ bool t_safe(float t) { return t == 0.0f || t >= 0x1p-100f; }
 
 enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3, kRelight = 4 };
@@ -306,23 +318,39 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
             float left = (float)it_limit;                  // per-lane countdown (exact: < 2^24)
             bool go;
             if (arith_mask) {
-                // face_mask by arithmetic instead of v_cmp + v_cndmask (full-rate VALU ops on gfx950):
-                // d = t - min >= 0 is 0 exactly when t == min (IEEE subtraction with denormals never rounds a
-                // non-zero difference to 0), and clamp(1 - d * 2^127) is 1 for d == 0 and 0 for d >= 2^-127,
-                // which holds for every non-zero d because all t are 0 or >= 2^-100 here (t_safe below).
+                // face_mask by arithmetic instead of v_cmp + v_cndmask (v_sub/v_mul/v_fma issue at ~1.6x the rate
+                // of compares, selects and min/max on gfx950; tools/ubench): d = t - min >= 0 is 0 exactly when
+                // t == min (IEEE subtraction with denormals never rounds a non-zero difference to 0), and
+                // clamp(1 - d * 2^127) is 1 for d == 0 and 0 for d >= 2^-127, which covers every non-zero d because
+                // all t are 0 or >= 2^-100 here (t_safe).  Two iterations per exit test: "alive" (1.0 / 0.0: no
+                // countdown reached 0 in the first iteration) replaces the constant 1.0 in the mask and the step
+                // count of the second one, so a lane that has left its node takes an empty second step.  The
+                // countdown test is a product (integers < 2^24: never rounds to zero) instead of min3 + min.
+                float gx, gy, gz, alive;
                 do {
-                    const float m = fminf(fminf(r.itx, r.ity), r.itz);
-                    fxf = unit_if_zero(r.itx - m);        // :558 (ties step several axes)
+                    float m = fminf(fminf(r.itx, r.ity), r.itz);
+                    fxf = unit_if_zero(r.itx - m);
                     fyf = unit_if_zero(r.ity - m);
                     fzf = unit_if_zero(r.itz - m);
-                    r.itx = __builtin_fmaf(r.dtx, fxf, r.itx);   // :559, exact: dt * {0,1} has no rounding
+                    r.itx = __builtin_fmaf(r.dtx, fxf, r.itx);
                     r.ity = __builtin_fmaf(r.dty, fyf, r.ity);
                     r.itz = __builtin_fmaf(r.dtz, fzf, r.itz);
-                    nx -= fxf; ny -= fyf; nz -= fzf;      // :560 as countdowns to the node face
+                    nx -= fxf; ny -= fyf; nz -= fzf;
                     left -= 1.0f;
-                    go = fminf(fminf(fminf(nx, ny), nz), left) != 0.0f;
-                    VRC_STAT(w_iters, 1);
+                    alive = mul_clamped(nx * ny, nz * left);
+                    m = fminf(fminf(r.itx, r.ity), r.itz);
+                    gx = alive_if_zero(r.itx - m, alive);
+                    gy = alive_if_zero(r.ity - m, alive);
+                    gz = alive_if_zero(r.itz - m, alive);
+                    r.itx = __builtin_fmaf(r.dtx, gx, r.itx);
+                    r.ity = __builtin_fmaf(r.dty, gy, r.ity);
+                    r.itz = __builtin_fmaf(r.dtz, gz, r.itz);
+                    nx -= gx; ny -= gy; nz -= gz;
+                    left -= alive;
+                    go = (nx * ny) * (nz * left) != 0.0f;
+                    VRC_STAT(w_iters, 2);
                 } while (go);
+                if (alive != 0.0f) { fxf = gx; fyf = gy; fzf = gz; }   // the mask of the last real iteration
             } else {
                 do {
                     const float m = fminf(fminf(r.itx, r.ity), r.itz);
