@@ -183,19 +183,23 @@ def test_edge_cases(case, using_octree, atlas):
 @pytest.mark.parametrize("make", [scenes.floor_pillars, scenes.random_sparse, scenes.app_default],
                          ids=["floor_pillars", "random_sparse", "app_default"])
 def test_step_loop_variants_agree(make, atlas):
-    """Setting arith_mask picks how the SVO step loop forms face_mask (v_cmp/v_cndmask or subtract + clamped fma):
-    a speed knob, same frame either way."""
+    """Settings arith_mask / safe_run pick how the SVO step loop forms face_mask (v_cmp/v_cndmask or subtract +
+    clamped fma) and whether lanes deep inside a node step without countdowns (csrc/safe_run.hpp): speed knobs,
+    same frame every way."""
     s = make()
     dim, w, h = s["dim"], 160, 120
     o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
     md = 20 if dim <= 16 else 3 * dim
     frames = []
-    for v in (0, 1):
+    for arith, safe, safe_steps in ((0, 0, 64), (1, 0, 64), (1, 1, 64), (1, 1, 256), (1, 1, 2)):
         c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
-        assert c.add_to_settings_buffer("arith_mask", "ARITH_MASK", v) and c.compute(), c.last_error()
+        assert c.add_to_settings_buffer("arith_mask", "ARITH_MASK", arith)
+        assert c.add_to_settings_buffer("safe_run", "SAFE_RUN", safe)
+        assert c.add_to_settings_buffer("safe_steps", "SAFE_STEPS", safe_steps) and c.compute(), c.last_error()
         frames.append((c.read_image(), c.read_hits(), c.counters()))
-    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
-    assert np.array_equal(frames[0][1], frames[1][1]) and frames[0][2] == frames[1][2]
+    for f in frames[1:]:
+        assert np.array_equal(frames[0][0].view(np.uint32), f[0].view(np.uint32))
+        assert np.array_equal(frames[0][1], f[1]) and frames[0][2] == f[2]
 
 
 def test_non_cubic_dense_map(atlas):

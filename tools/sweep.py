@@ -17,10 +17,10 @@ def main():
     c.add_to_settings_buffer(name, name.upper(), values[0])
     for v in values:
         c.overwrite_setting(name, v)
-        for _ in range(2):
+        for _ in range(3):
             assert c.compute(), c.last_error()
         c.timing_reset()
-        for _ in range(5):
+        for _ in range(10):
             assert c.compute()
         n, ms = c.timing()
         ctr = c.counters()

@@ -84,12 +84,33 @@ __global__ __launch_bounds__(256, 6) void k_floor(float *out, int iters) {
     FINISH
 }
 
+// "safe run": no countdowns; a lane steps while the crossing time m is below a threshold T (alive = clamp((T - m) * B1)),
+// all lanes execute every trip (a lane that is done takes empty steps), loop control is scalar
+__global__ __launch_bounds__(256, 6) void k_safe(float *out, int iters) {
+    SETUP
+    const float T = 1e30f, B1 = 0x1p-70f, TB1 = T * B1;
+    float cnt = 0.0f, alive = 1.0f;
+    for (int trip = 0; trip < iters / 2; trip++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const float m = fminf(fminf(itx, ity), itz);
+            asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(alive) : "v"(m), "v"(-B1), "v"(TB1));
+            cnt += alive;
+            fxf = alive_if_zero(itx - m, alive); fyf = alive_if_zero(ity - m, alive); fzf = alive_if_zero(itz - m, alive);
+            itx = __builtin_fmaf(dtx, fxf, itx); ity = __builtin_fmaf(dty, fyf, ity); itz = __builtin_fmaf(dtz, fzf, itz);
+        }
+        if (__ballot(alive != 0.0f) == 0ULL) break;
+    }
+    nx -= cnt;
+    FINISH
+}
+
 typedef void (*kern_t)(float *, int);
 int main() {
     struct { const char *name; kern_t k; int valu; } ks[] = {
         {"cmp/cndmask mask, min exit (old loop)", k_cmp, 17}, {"arith mask, min exit (arith_mask=1)", k_arith, 17},
         {"arith mask, product exit", k_arith_prod, 17}, {"2 iterations per exit test (arith_mask=2)", k_alive2, 0},
-        {"recurrence only, scalar trip count", k_floor, 13}};
+        {"recurrence only, scalar trip count", k_floor, 13}, {"safe run (threshold on t, no countdowns)", k_safe, 12}};
     hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0);
     const int blocks = prop.multiProcessorCount * 6;     // 6 blocks x 4 waves per CU = 6 waves per SIMD
     float *out; (void)hipMalloc(&out, sizeof(float) * blocks * 256);

@@ -34,6 +34,7 @@
 
 #include "exact_jump.hpp"
 #include "raycast_common.hpp"
+#include "safe_run.hpp"
 
 namespace vrc {
 
@@ -104,26 +105,6 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
 // ---------------------------------------------------------------------------
 // SVO branch
 // ---------------------------------------------------------------------------
-// 1.0 when d == 0, 0.0 when d >= 2^-127 (one full-rate VALU op: v_fma_f32 with the clamp modifier)
-__device__ __forceinline__ float unit_if_zero(float d) {
-    float f;
-    asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(f) : "v"(d), "s"(-0x1p127f));
-    return f;
-}
-// as unit_if_zero, but 0.0 for every d >= 0 when alive == 0.0 (alive is 1.0 or 0.0)
-__device__ __forceinline__ float alive_if_zero(float d, float alive) {
-    float f;
-    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(f) : "v"(d), "s"(-0x1p127f), "v"(alive));
-    return f;
-}
-// min(a * b, 1) for a, b >= 0
-__device__ __forceinline__ float mul_clamped(float a, float b) {
-    float f;
-    asm("v_mul_f32 %0, %1, %2 clamp" : "=v"(f) : "v"(a), "v"(b));
-    return f;
-}
-__device__ __forceinline__ bool t_safe(float t) { return t == 0.0f || t >= 0x1p-100f; }
-
 enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3, kRelight = 4 };
 
 // kJump: also use the closed-form multi-iteration jumps of exact_jump.hpp (opt-in, setting jump_min_run)
@@ -256,6 +237,8 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
 
     const int shade_threshold = p.shade_threshold;
     const float jump_min_run = (float)p.jump_min_run;
+    const int exact_cap = (!kJump && p.arith_mask != 0 && p.safe_run != 0) ? p.exact_steps : p.burst_steps;
+    const int safe_cap = p.safe_steps;                   // iterations per safe run (phase 2a)
     const int burst_cap = p.burst_steps;                 // ordinary steps per round and lane
     JumpCache jcache;
     jump_cache_reset(jcache);
@@ -306,14 +289,58 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
         // the arithmetic face_mask of the step loop needs every t to be 0 or >= 2^-100.  t only grows by
         // delta_t >= 1/2 per step, so once a lane is safe it stays safe until its ray is restarted (t_unsafe is set
         // again there); a wave with an unsafe stepping lane takes the compare/select loop for this burst.
-        if (t_unsafe) t_unsafe = !(t_safe(r.itx) && t_safe(r.ity) && t_safe(r.itz));
+        if (t_unsafe) t_unsafe = !(t_is_safe(r.itx) && t_is_safe(r.ity) && t_is_safe(r.itz));
         const bool arith_mask = p.arith_mask != 0 && __ballot(mode == kStep && t_unsafe) == 0ULL;
+
+        // ---- phase 2a: safe run (safe_run.hpp): lanes deep inside an empty node step without countdowns while
+        // min(t) is below their threshold T.  All lanes run every trip (a lane whose gate is closed takes empty
+        // steps): no exec masking, scalar loop control.
+        if (!kJump && arith_mask && p.safe_run != 0) {
+            SafeGate gate;
+            if (mode == kStep && r.max_distance - r.distance_traveled >= safe_cap) {
+                const float T = fminf(fminf(safe_threshold(r.itx, r.dtx, nx), safe_threshold(r.ity, r.dty, ny)),
+                                      safe_threshold(r.itz, r.dtz, nz));
+                gate = make_gate(T, fminf(fminf(r.itx, r.ity), r.itz));
+            }
+            if (__ballot(gate.open) != 0ULL) {
+                const float x0 = r.itx, y0 = r.ity, z0 = r.itz;
+                float cnt = 0.0f, alive;
+#pragma nounroll
+                for (int trip = safe_cap >> 1; trip > 0; trip--) {
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const float m = fminf(fminf(r.itx, r.ity), r.itz);
+                        alive = fma_sat(m, gate.neg_b1, gate.tb1);
+                        cnt += alive;
+                        const float gx = alive_if_zero(r.itx - m, alive);    // :558
+                        const float gy = alive_if_zero(r.ity - m, alive);
+                        const float gz = alive_if_zero(r.itz - m, alive);
+                        r.itx = __builtin_fmaf(r.dtx, gx, r.itx);            // :559
+                        r.ity = __builtin_fmaf(r.dty, gy, r.ity);
+                        r.itz = __builtin_fmaf(r.dtz, gz, r.itz);
+                    }
+                    VRC_STAT(w_iters, 2);
+#ifdef VRC_SCHED_STATS
+                    if (lane_id == 0) l_try += 2;         // safe-run wave-iterations (reported as jump_attempts)
+                    l_ok += (unsigned)alive + (unsigned)alive;   // ~ safe-run lane-iterations (jump_successes)
+#endif
+                    if (__ballot(alive != 0.0f) == 0ULL) break;
+                }
+                if (gate.open) {
+                    nx -= safe_steps_taken(r.itx, x0, r.rdx);                // :560 as countdowns
+                    ny -= safe_steps_taken(r.ity, y0, r.rdy);
+                    nz -= safe_steps_taken(r.itz, z0, r.rdz);
+                    r.distance_traveled += (int)cnt;                         // :714
+                    if (r.distance_traveled >= r.max_distance) mode = ended();   // :357
+                }
+            }
+        }
 
         // ---- phase 2: ordinary steps (:357-560) for lanes still inside their node.  A lane that is waiting
         // to jump only takes two steps (enough to settle its progressions); the others run to their node face.
         if (mode == kStep) {
             const int true_limit = r.max_distance - r.distance_traveled;     // >= 1 iterations left (:357)
-            const int cap = (kJump && fminf(fminf(nx, ny), nz) >= jump_min_run) ? 2 : burst_cap;
+            const int cap = (kJump && fminf(fminf(nx, ny), nz) >= jump_min_run) ? 2 : exact_cap;
             const int it_limit = true_limit < cap ? true_limit : cap;
             float left = (float)it_limit;                  // per-lane countdown (exact: < 2^24)
             bool go;
@@ -329,15 +356,15 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                 float gx, gy, gz, alive;
                 do {
                     float m = fminf(fminf(r.itx, r.ity), r.itz);
-                    fxf = unit_if_zero(r.itx - m);
-                    fyf = unit_if_zero(r.ity - m);
-                    fzf = unit_if_zero(r.itz - m);
+                    fxf = alive_if_zero(r.itx - m, 1.0f);
+                    fyf = alive_if_zero(r.ity - m, 1.0f);
+                    fzf = alive_if_zero(r.itz - m, 1.0f);
                     r.itx = __builtin_fmaf(r.dtx, fxf, r.itx);
                     r.ity = __builtin_fmaf(r.dty, fyf, r.ity);
                     r.itz = __builtin_fmaf(r.dtz, fzf, r.itz);
                     nx -= fxf; ny -= fyf; nz -= fzf;
                     left -= 1.0f;
-                    alive = mul_clamped(nx * ny, nz * left);
+                    alive = mul_sat(nx * ny, nz * left);
                     m = fminf(fminf(r.itx, r.ity), r.itz);
                     gx = alive_if_zero(r.itx - m, alive);
                     gy = alive_if_zero(r.ity - m, alive);
