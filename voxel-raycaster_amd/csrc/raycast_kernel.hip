@@ -238,6 +238,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
     const int shade_threshold = p.shade_threshold;
     const float jump_min_run = (float)p.jump_min_run;
     const int exact_cap = (!kJump && p.arith_mask != 0 && p.safe_run != 0) ? p.exact_steps : p.burst_steps;
+    const float safe_limit = safe_t_limit(p.safe_steps);
     const int safe_cap = p.safe_steps;                   // iterations per safe run (phase 2a)
     const int burst_cap = p.burst_steps;                 // ordinary steps per round and lane
     JumpCache jcache;
@@ -295,12 +296,13 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
         // ---- phase 2a: safe run (safe_run.hpp): lanes deep inside an empty node step without countdowns while
         // min(t) is below their threshold T.  All lanes run every trip (a lane whose gate is closed takes empty
         // steps): no exec masking, scalar loop control.
+        bool deep = false;                                // still far from the node face after the safe run
         if (!kJump && arith_mask && p.safe_run != 0) {
             SafeGate gate;
             if (mode == kStep && r.max_distance - r.distance_traveled >= safe_cap) {
                 const float T = fminf(fminf(safe_threshold(r.itx, r.dtx, nx), safe_threshold(r.ity, r.dty, ny)),
                                       safe_threshold(r.itz, r.dtz, nz));
-                gate = make_gate(T, fminf(fminf(r.itx, r.ity), r.itz));
+                gate = make_gate(T, fminf(fminf(r.itx, r.ity), r.itz), safe_limit);
             }
             if (__ballot(gate.open) != 0ULL) {
                 const float x0 = r.itx, y0 = r.ity, z0 = r.itz;
@@ -332,13 +334,15 @@ __global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const Ray
                     nz -= safe_steps_taken(r.itz, z0, r.rdz);
                     r.distance_traveled += (int)cnt;                         // :714
                     if (r.distance_traveled >= r.max_distance) mode = ended();   // :357
+                    deep = alive != 0.0f;
                 }
             }
         }
 
         // ---- phase 2: ordinary steps (:357-560) for lanes still inside their node.  A lane that is waiting
         // to jump only takes two steps (enough to settle its progressions); the others run to their node face.
-        if (mode == kStep) {
+        // (skipped when every stepping lane of the wave is still deep inside its node: the next safe run takes them on)
+        if (mode == kStep && __ballot(mode == kStep && !deep) != 0ULL) {
             const int true_limit = r.max_distance - r.distance_traveled;     // >= 1 iterations left (:357)
             const int cap = (kJump && fminf(fminf(nx, ny), nz) >= jump_min_run) ? 2 : exact_cap;
             const int it_limit = true_limit < cap ? true_limit : cap;

@@ -15,8 +15,8 @@
 //    each step rounds by at most 2^-24 relative.  Every iteration with min(t) < T := min_a T_a therefore stays
 //    inside the node: the lane steps while alive = clamp((T - min t) * B1) is 1, with B1 = 2^(24-e) for
 //    2^e <= T < 2^(e+1) (floats below T are at least 2^(e-24) away, so the product is >= 1), and counts its
-//    iterations.  Afterwards the steps taken per axis are rint((t_a - t_a0) * |ray_dir_a|): with T < 2^13 the
-//    recurrence drifts by less than kSafeMaxSteps * ulp(2^14) / 2 = 0.125 steps.
+//    iterations.  Afterwards the steps taken per axis are rint((t_a - t_a0) * |ray_dir_a|): a stepped t stays below
+//    2T, so k iterations drift by at most k * ulp(2T) / 2 <= 1/8 step when T < 2^21 / k (safe_t_limit).
 //
 // Host+device header: tools/jumptest/safe_vs_loop.cpp drives the host build against the plain loop
 // (tests/test_safe_run.py); raycast_kernel.hip uses the device build.
@@ -33,7 +33,14 @@
 
 namespace vrc {
 
-constexpr int kSafeMaxSteps = 256;     // iterations per safe run the recovery bound above allows
+constexpr int kSafeMaxSteps = 256;     // most iterations per safe run the settings allow
+
+// largest threshold T a safe run of at most `steps` iterations may use (see the recovery bound above)
+VRC_SR float safe_t_limit(int steps) {
+    int k = 1;
+    while (k < steps) k <<= 1;
+    return 0x1p21f / (float)k;
+}
 
 // clamp(a * b + c) to [0, 1], NaN -> 0: one v_fma_f32 with the clamp modifier on the device
 VRC_SR float fma_sat(float a, float b, float c) {
@@ -68,9 +75,9 @@ VRC_SR float safe_threshold(float t, float dt, float n) { return fmaf(n - 1.0f, 
 // alive = fma_sat(min_t, neg_b1, tb1).  The default gate is closed for every value of t, NaN and inf included.
 struct SafeGate { float neg_b1 = 0.0f, tb1 = -1.0f; bool open = false; };
 
-VRC_SR SafeGate make_gate(float T, float min_t) {
+VRC_SR SafeGate make_gate(float T, float min_t, float t_limit) {
     SafeGate g;
-    if (T >= 0x1p-60f && T < 0x1p13f && min_t < T) {
+    if (T >= 0x1p-60f && T < t_limit && min_t < T) {
         union { float f; uint32_t u; } c;
         c.f = T;
         c.u = (278u - (c.u >> 23)) << 23;          // 2^(24-e) for 2^e <= T < 2^(e+1)
