@@ -105,13 +105,16 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
 // ---------------------------------------------------------------------------
 // SVO branch
 // ---------------------------------------------------------------------------
+#ifndef VRC_MIN_BLOCKS
+#define VRC_MIN_BLOCKS 6            // 256-thread blocks per CU the register budget allows (6 waves per SIMD)
+#endif
 enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3, kRelight = 4 };
 
 // kJump: also use the closed-form multi-iteration jumps of exact_jump.hpp (opt-in, setting jump_min_run)
 // kMulti: multi-light extension (setting light_count > 1): a finished shadow ray parks the lane in kRelight and
 //         the shade phase restarts it from the first strike toward the next light
 template <bool kJump, bool kMulti>
-__global__ __launch_bounds__(kBlockThreads, 6) void raycast_svo_kernel(const RaycastParams p) {
+__global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
     __shared__ unsigned long long block_ctr[kCtrCount];
     const int tid = threadIdx.x;
