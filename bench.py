@@ -260,6 +260,15 @@ def main():
         traffic = None        # HBM bytes per launch from the committed PMC passes (N=1 headline workload only)
         if world == 1 and args.depth == 12 and (W, H) == (1920, 1080) and args.pmc_traffic and os.path.exists(args.pmc_traffic):
             traffic = json.load(open(args.pmc_traffic)).get("hbm_bytes_per_launch")
+        # what actually bounds the kernel: VALU issue.  The float recurrence of ray_caster_kernel.cl:558-559 (min, three
+        # masks, three fused updates = 10 wave64 instructions per 64 lane steps) is the floor of any bit-exact
+        # stepping kernel; valu_floor_frac = that floor / the VALU instructions the kernel issues (PMC).
+        issue = None
+        if traffic is not None:
+            valu = json.load(open(args.pmc_traffic)).get("valu_insts_per_launch")
+            if valu:
+                floor = ctr["steps"] / 64.0 * 10.0
+                issue = {"valu_insts_per_launch": int(valu), "floor_insts": int(floor), "valu_floor_frac": round(floor / valu, 4)}
         out = {
             "metric": "Mrays/s (primary+shadow), 1920x1080 into depth-12 SVO",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -276,7 +285,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel": "raycast_svo_kernel",
                          "note": "exact-parity stepping is VALU-issue bound (DESIGN.md 4): 8.4 G DDA steps vs 74 M descriptor reads per frame",
-                         "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"]},
+                         "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"], "valu_issue": issue},
         }
         if world == 1 and not args.no_cpu_baseline:
             rays, secs, used, cores, nrows, same = cpu_baseline(sc, W, H, gpu_frame=c.read_image())
