@@ -365,6 +365,36 @@ def test_multi_light_baseline_geometry_sampled_rows(w, h, n):
         assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
 
 
+POSES = [  # (cam_dir, camera offset from the bench pose in voxels)
+    ((1.5708, 0.0), (0.0, 0.0, 0.0)),            # straight along an axis: sin(yaw) == 0 column is never written, many exact ties
+    ((3.05, 0.7854), (100.5, -200.25, 1500.0)),  # from high above, looking down: t up to ~2^13
+    ((0.35, 2.3), (0.0, 0.0, -60.0)),            # low over the terrain, looking up into the sky
+    ((2.0, 4.0), (-1900.0, 3400.0, 700.0)),      # from near the far corner, back across the map
+    ((2.2, 1.5708), (0.0, -4000.0, 200.0)),      # camera outside the map (negative y), looking in
+]
+
+
+@pytest.mark.parametrize("pose", range(len(POSES)))
+def test_headline_scene_other_cameras(pose):
+    """The depth-12 bench scene from other camera poses (the step-loop variants of DESIGN 4 depend on the ray mix:
+    long safe runs, rays entering from outside, grazing rays): sampled rows bit-exact vs the oracle."""
+    sc = _bench_scene(12)
+    dim, w, h = sc["dim"], 640, 360
+    cam_dir, off = POSES[pose]
+    cam_pos = tuple(float(a + b) for a, b in zip(sc["cam_pos"], off))
+    c = make_caster(sc["octree"], dim, 0, cam_dir, cam_pos, sc["lights"], sc["atlas"], w, h, 3 * dim)
+    assert c.compute(), c.last_error()
+    img, hits, ctr = c.read_image(), c.read_hits(), c.counters()
+    assert ctr["descriptor_reads"] == int(hits[..., 7].sum())
+    for y0 in range(7, h, 59):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=sc["atlas"],
+                                     tile_dim=(16, 16), descriptors=sc["octree"].descriptor_buffer,
+                                     root_index=sc["octree"].root_index, octree_dim=dim, using_octree=0,
+                                     max_distance=3 * dim, rows=(y0, y0 + 1), threads=8)
+        assert np.array_equal(hits[y0], ohits[y0])
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+
+
 def test_depth13_scene_sampled_rows():
     """Beyond the headline: 8192^3 (depth 13), 84 M descriptors (674 MB), thousands of far pointers and page
     headers, 12 stack levels in LDS -- sampled rows bit-exact vs the oracle, counters consistent."""
