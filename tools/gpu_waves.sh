@@ -1,4 +1,4 @@
-# kernel time of the headline frame for builds with different __launch_bounds__ minimum blocks (libvrc_w<N>.so)
+# kernel time of the headline frame for builds with different __launch_bounds__ minimum blocks: build libvrc_w<N>.so with -DVRC_MIN_BLOCKS=<N> first
 cp voxel-raycaster_amd/libvrc.so /tmp/libvrc_prod.so
 for w in "$@"; do
   cp voxel-raycaster_amd/libvrc_w$w.so voxel-raycaster_amd/libvrc.so
