@@ -415,6 +415,45 @@ def test_depth13_scene_sampled_rows():
         assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
 
 
+def test_depth14_scene_sampled_rows():
+    """16384^3 (depth 14): 345 M descriptors (2.8 GB), 13 stack levels in LDS, t values up to 2^15 -- sampled rows
+    bit-exact vs the oracle."""
+    sc = _bench_scene(14)
+    w, h, dim = 1920, 1080, sc["dim"]
+    d = sc["octree"].descriptor_buffer
+    assert d.size > 300_000_000
+    c = make_caster(sc["octree"], dim, 0, sc["cam_dir"], sc["cam_pos"], sc["lights"], sc["atlas"], w, h, 3 * dim)
+    assert c.compute(), c.last_error()
+    img, hits, ctr = c.read_image(), c.read_hits(), c.counters()
+    assert ctr["descriptor_reads"] == int(hits[..., 7].sum()) and ctr["primary_rays"] == w * h
+    for y0 in (61, 533, 1002):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=c._li,
+                                     atlas=sc["atlas"], tile_dim=(16, 16), descriptors=d, root_index=sc["octree"].root_index,
+                                     octree_dim=dim, using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=8)
+        assert np.array_equal(hits[y0], ohits[y0])
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+
+
+@pytest.mark.skipif(os.environ.get("VRC_DEEP_TESTS") != "1", reason="builds a 45 GB SVO (3.5 min, 165 GB host RSS): set VRC_DEEP_TESTS=1")
+def test_depth16_scene_sampled_rows():
+    """BASELINE configs[4] depth: 65536^3, 5.69 G descriptors = 45.5 GB resident in HBM, 15 stack levels in LDS, far
+    pointers beyond 2^32 -- sampled rows of a 1920x1080 frame bit-exact vs the oracle."""
+    sc = _bench_scene(16)
+    w, h, dim = 1920, 1080, sc["dim"]
+    d = sc["octree"].descriptor_buffer
+    assert d.size > (1 << 32)
+    c = make_caster(sc["octree"], dim, 0, sc["cam_dir"], sc["cam_pos"], sc["lights"], sc["atlas"], w, h, 3 * dim)
+    assert c.compute(), c.last_error()
+    img, hits, ctr = c.read_image(), c.read_hits(), c.counters()
+    assert ctr["descriptor_reads"] == int(hits[..., 7].sum()) and ctr["primary_rays"] == w * h
+    for y0 in (97, 540, 983):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=c._li,
+                                     atlas=sc["atlas"], tile_dim=(16, 16), descriptors=d, root_index=sc["octree"].root_index,
+                                     octree_dim=dim, using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=8)
+        assert np.array_equal(hits[y0], ohits[y0])
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+
+
 def test_headline_config_full_size_properties():
     """BASELINE configs[2] at full size (depth-12 SVO, 1920x1080, primary + shadow + shading):
     sampled rows bit-exact vs the oracle, idempotence, tiling invariance, counter identities."""

@@ -328,7 +328,7 @@ int vrc_octree_generate(const int8_t *grid, uint32_t dim, uint64_t buffer_size, 
 int vrc_scene_shell_terrain(uint32_t depth, uint64_t seed, int32_t thickness, int strict_reference,
                             uint64_t **descriptors, uint64_t *n_descriptors, uint64_t *root_index,
                             int32_t *height) {
-    if (depth < 3 || depth > 13 || !descriptors || !n_descriptors || !root_index) return VRC_ERR_INVALID_ARGUMENT;
+    if (depth < 3 || depth > 16 || !descriptors || !n_descriptors || !root_index) return VRC_ERR_INVALID_ARGUMENT;
     std::vector<int32_t> h;
     make_heightfield(depth, seed, h);
     if (height) memcpy(height, h.data(), h.size() * sizeof(int32_t));
@@ -365,7 +365,7 @@ int vrc_octree_attachments_from_grid(const int8_t *grid, uint32_t dim, const uin
 int vrc_scene_shell_terrain_attachments(uint32_t depth, uint64_t seed, uint32_t mirror_period, const uint64_t *descriptors,
                                         uint64_t n_descriptors, uint64_t root_index, uint32_t **lookup,
                                         uint64_t **attachments, uint64_t *n_attachments) {
-    if (depth < 3 || depth > 13 || !descriptors || !lookup || !attachments || !n_attachments || root_index >= n_descriptors)
+    if (depth < 3 || depth > 15 || !descriptors || !lookup || !attachments || !n_attachments || root_index >= n_descriptors)
         return VRC_ERR_INVALID_ARGUMENT;
     // material 6 (mirror) where hash(x,y,z,seed) % mirror_period == 0, else 5; 0 = no mirrors
     auto mat = [seed, mirror_period](int x, int y, int z) -> int8_t {
