@@ -202,6 +202,23 @@ def test_step_loop_variants_agree(make, atlas):
         assert np.array_equal(frames[0][1], f[1]) and frames[0][2] == f[2]
 
 
+def test_unnormalised_ray_table(atlas):
+    """A host-supplied ray table need not be normalised (vrc_create_viewport_table): delta_t = |1/dir| then falls
+    below 1 and the safe run must stand aside (csrc/safe_run.hpp); longer-than-unit and shorter-than-unit rays, SVO."""
+    s = scenes.random_sparse()
+    dim, w, h, md = s["dim"], 128, 96, 3 * s["dim"]
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+    table = orc.create_viewport(w, h).reshape(h, w, 4).copy()
+    table[: h // 3] *= np.float32(2.5)
+    table[h // 3: 2 * h // 3] *= np.float32(0.4)
+    c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+    assert c.create_viewport_table(table) and c.validate() and c.compute(), c.last_error()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=c._li, atlas=atlas,
+                                    tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                    octree_dim=dim, using_octree=0, max_distance=md, viewport=table)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+
+
 def test_non_cubic_dense_map(atlas):
     """The array branch takes any dx,dy,dz (kernel index x + dx*(y + dz*z), ray_caster_kernel.cl:569)."""
     dx, dy, dz = 24, 16, 16                       # dy == dz keeps the reference's dim.z-as-y-stride quirk in bounds

@@ -28,10 +28,11 @@ int main(int argc, char **argv) {
         if (kind == 1) { rd[1] = rd[0]; rd[2] = -rd[0]; }
         float len = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
         bool ok = len > 0.0f;
-        for (int a = 0; a < 3; a++) { rd[a] /= len; ok = ok && rd[a] != 0.0f; }
+        const float scale = kind == 4 ? 0.3f + 2.7f * U(rng) : 1.0f;                   // host-supplied tables need not be normalised
+        for (int a = 0; a < 3; a++) { rd[a] = rd[a] / len * scale; ok = ok && rd[a] != 0.0f; }
         if (!ok) { c--; continue; }
         float dt[3], t[3], n[3];
-        const float travelled = (kind == 2 ? 70000.0f : 6000.0f) * U(rng) * U(rng);    // also beyond safe_t_limit
+        const float travelled = (kind == 2 ? 140000.0f : 6000.0f) * U(rng) * U(rng);    // also beyond safe_t_limit
         const int node = 1 << (int)(U(rng) * 11.0f);
         for (int a = 0; a < 3; a++) {
             dt[a] = fabsf(1.0f / rd[a]);
@@ -47,7 +48,7 @@ int main(int argc, char **argv) {
         if (!(t_is_safe(s[0]) && t_is_safe(s[1]) && t_is_safe(s[2]))) continue;
         const float T = fminf(fminf(safe_threshold(s[0], dt[0], n[0]), safe_threshold(s[1], dt[1], n[1])),
                               safe_threshold(s[2], dt[2], n[2]));
-        const SafeGate gate = make_gate(T, fminf(fminf(s[0], s[1]), s[2]), safe_t_limit(cap));
+        const SafeGate gate = make_gate(T, fminf(fminf(s[0], s[1]), s[2]), safe_t_limit(cap), fminf(fminf(dt[0], dt[1]), dt[2]));
         float cnt = 0.0f;
         for (int i = 0; i < cap; i++) {
             const float m = fminf(fminf(s[0], s[1]), s[2]);

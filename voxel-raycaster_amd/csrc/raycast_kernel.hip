@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
             if (mode == kStep && r.max_distance - r.distance_traveled >= safe_cap) {
                 const float T = fminf(fminf(safe_threshold(r.itx, r.dtx, nx), safe_threshold(r.ity, r.dty, ny)),
                                       safe_threshold(r.itz, r.dtz, nz));
-                gate = make_gate(T, fminf(fminf(r.itx, r.ity), r.itz), safe_limit);
+                gate = make_gate(T, fminf(fminf(r.itx, r.ity), r.itz), safe_limit, fminf(fminf(r.dtx, r.dty), r.dtz));
             }
             if (__ballot(gate.open) != 0ULL) {
                 const float x0 = r.itx, y0 = r.ity, z0 = r.itz;

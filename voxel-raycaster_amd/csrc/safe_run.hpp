@@ -16,7 +16,7 @@
 //    inside the node: the lane steps while alive = clamp((T - min t) * B1) is 1, with B1 = 2^(24-e) for
 //    2^e <= T < 2^(e+1) (floats below T are at least 2^(e-24) away, so the product is >= 1), and counts its
 //    iterations.  Afterwards the steps taken per axis are rint((t_a - t_a0) * |ray_dir_a|): a stepped t stays below
-//    2T, so k iterations drift by at most k * ulp(2T) / 2 <= 1/8 step when T < 2^21 / k (safe_t_limit).
+//    2T, so k iterations drift by at most k * ulp(2T) / 2 <= 1/4 step when T < 2^22 / k (safe_t_limit) and delta_t >= 1.
 //
 // Host+device header: tools/jumptest/safe_vs_loop.cpp drives the host build against the plain loop
 // (tests/test_safe_run.py); raycast_kernel.hip uses the device build.
@@ -39,7 +39,7 @@ constexpr int kSafeMaxSteps = 256;     // most iterations per safe run the setti
 VRC_SR float safe_t_limit(int steps) {
     int k = 1;
     while (k < steps) k <<= 1;
-    return 0x1p21f / (float)k;
+    return 0x1p22f / (float)k;
 }
 
 // clamp(a * b + c) to [0, 1], NaN -> 0: one v_fma_f32 with the clamp modifier on the device
@@ -75,9 +75,11 @@ VRC_SR float safe_threshold(float t, float dt, float n) { return fmaf(n - 1.0f, 
 // alive = fma_sat(min_t, neg_b1, tb1).  The default gate is closed for every value of t, NaN and inf included.
 struct SafeGate { float neg_b1 = 0.0f, tb1 = -1.0f; bool open = false; };
 
-VRC_SR SafeGate make_gate(float T, float min_t, float t_limit) {
+// min_dt: the smallest delta_t of the ray; the recovery bound needs delta_t >= 1 (|ray_dir| <= 1: the reference's rays
+// are normalised, a host-supplied ray table need not be)
+VRC_SR SafeGate make_gate(float T, float min_t, float t_limit, float min_dt) {
     SafeGate g;
-    if (T >= 0x1p-60f && T < t_limit && min_t < T) {
+    if (T >= 0x1p-60f && T < t_limit && min_t < T && min_dt >= 0.999f) {
         union { float f; uint32_t u; } c;
         c.f = T;
         c.u = (278u - (c.u >> 23)) << 23;          // 2^(24-e) for 2^e <= T < 2^(e+1)
