@@ -1,6 +1,6 @@
 # depth-16 probe with an RSS watchdog (the box's cgroup allows ~300 GiB): bash tools/gpu_deep16.sh
 mkdir -p gpurun_out
-python tools/deep_scene_probe.py 16 > gpurun_out/deep16.log 2>&1 &
+python tools/deep_scene_probe.py 16 ${1:-1920} ${2:-1080} ${3:-1} > gpurun_out/deep16.log 2>&1 &
 PID=$!
 PEAK=0
 while kill -0 $PID 2>/dev/null; do
