@@ -305,8 +305,8 @@ __device__ __forceinline__ void block_pixel(const RaycastParams &p, int &px, int
     const int band = local_ty / p.band_tiles;
     const int tile_y = (band * p.tile_world + p.tile_rank) * p.band_tiles + (local_ty - band * p.band_tiles);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    px = (bx * kTilesPerBlock + wave) * kTileW + (lane & 7);
-    py = tile_y * kTileH + (lane >> 3);
+    px = (bx * kTilesPerBlock + wave) * kTileW + (lane & (kTileW - 1));
+    py = tile_y * kTileH + lane / kTileW;
 }
 
 // per-block counter partials (no global atomics): wave shuffle reduce, LDS, one row per block

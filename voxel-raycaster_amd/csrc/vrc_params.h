@@ -8,8 +8,12 @@
 
 namespace vrc {
 
-constexpr int kTileW = 8;             // one wavefront = one 8x8 pixel tile
-constexpr int kTileH = 8;
+#ifndef VRC_TILE_W
+#define VRC_TILE_W 8
+#endif
+constexpr int kTileW = VRC_TILE_W;    // one wavefront = one kTileW x kTileH pixel tile (8x8)
+constexpr int kTileH = 64 / VRC_TILE_W;
+static_assert((kTileW & (kTileW - 1)) == 0 && kTileW >= 1 && kTileW <= 64, "tile width must be a power of two <= 64");
 constexpr int kTilesPerBlock = 4;     // 256-thread block = 4 horizontally adjacent tiles (32x8 px)
 constexpr int kBlockThreads = 64 * kTilesPerBlock;
 constexpr int kMaxLights = 8;         // light slots (include/LightController.h:95)
