@@ -73,6 +73,8 @@ lib.orc_create_viewport.restype = None
 lib.orc_create_viewport.argtypes = [C.c_int32, C.c_int32, _f32p]
 lib.orc_camera_trig.restype = None
 lib.orc_camera_trig.argtypes = [_f32p, _f32p]
+lib.orc_view_light.restype = None
+lib.orc_view_light.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _i32p]
 lib.orc_raycast.restype = None
 lib.orc_raycast.argtypes = [C.POINTER(Scene), C.c_int32, C.c_int32, _f32p, _i32p, C.POINTER(Counters), C.c_int]
 lib.orc_clear_image.restype = None
@@ -105,6 +107,15 @@ def get_oct_vox(position, descriptors: np.ndarray, root_index: int, dim: int) ->
     pos = (C.c_int32 * 3)(*[int(v) for v in position])
     lib.orc_get_oct_vox(pos, _p(descriptors, _u64p), root_index, dim, C.byref(ts))
     return ts
+
+
+def view_light(in_color, light, light_color, view, mask) -> np.ndarray:
+    """view_light (ray_caster_kernel.cl:78-99) for one case."""
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (in_color, light, light_color, view)]
+    m = np.ascontiguousarray(mask, dtype=np.int32)
+    out = np.zeros(4, dtype=np.float32)
+    lib.orc_view_light(_p(out, _f32p), _p(a[0], _f32p), _p(a[1], _f32p), _p(a[2], _f32p), _p(a[3], _f32p), _p(m, _i32p))
+    return out
 
 
 def octree_validate(grid, dim, descriptors, root_index) -> int:

@@ -291,6 +291,12 @@ static void view_light(float out[4], const float in_color[4], const float light[
         out[c] = in_color[c] + (diffuse * light_color[c] + specular * light_color[c] / d);
 }
 
+void orc_view_light(float out[4], const float in_color[4], const float light[3], const float light_color[4],
+                    const float view[3], const int32_t mask[3]) {
+    const int m[3] = {mask[0], mask[1], mask[2]};
+    view_light(out, in_color, light, light_color, view, m);
+}
+
 void orc_camera_trig(const float cam_dir[2], float trig[4]) {
     trig[0] = sinf(cam_dir[0]);
     trig[1] = cosf(cam_dir[0]);

@@ -13,22 +13,22 @@
  * load this library, and only as the checker.  The product (libvrc.so) never
  * links or calls it.
  *
- * PARITY UNPINNED.  The reference ships no tests, golden vectors or fixtures
- * (SURVEY 4), and none of it can execute in this image without writing
- * stand-ins, which is not allowed: the host code (Octree.cpp, CLCaster.cpp,
- * Ray.cpp) needs SFML/OpenCL/GL headers and libraries the image lacks, and the
- * kernel -- which does compile unmodified for gfx950 with the image's own
- * OpenCL device libraries -- has no observable output on an MI355X because
- * CDNA4 has no image hardware: read_imagef/write_imagef lower to no-ops and
- * the AMD OpenCL runtime refuses clCreateImage (CL_INVALID_OPERATION); evidence
- * in profiles/r01_reference_kernel_on_gfx950.txt.  This file is therefore a
- * line-by-line restatement (each block cites the reference line it follows)
- * checked by (a) the reference's own self-check Octree::Validate
- * (src/map/Octree.cpp:329-352), (b) a second, independently written builder
- * in the product (bit-identical output), (c) Ray::Cast's constant known
- * answer, (d) array-branch == SVO-occupancy equality on the same grid.
- * tests/golden/orc_*.npz are regression vectors produced by THIS oracle, not
- * by the reference.  See DESIGN.md "Oracle and pinning".
+ * PARTLY PINNED.  get_oct_vox (a3) and view_light (the shading arithmetic of a6) are pinned against the
+ * reference's own code: kernels/ray_caster_kernel.cl compiles unmodified for gfx950, oracle/ref_probe.cl includes it
+ * from /root/reference and calls the two functions from probe kernels, and tests/test_reference_pin_gpu.py
+ * compares them with this file on the MI355X (get_oct_vox: every field equal; view_light: 99.98 % of cases within
+ * 1e-5 relative, worst 3.1e-5 -- the OpenCL library's normalize/fast_length are approximate).
+ * PARITY UNPINNED for the rest (a2 builder, a4 ray table, a5 step loop, UV/texel/redirect code of a6, a7): the
+ * reference ships no tests, golden vectors or fixtures, its host code (Octree.cpp, CLCaster.cpp,
+ * Ray.cpp) needs SFML/OpenCL/GL headers and libraries the image lacks (writing stand-ins is not allowed), and its
+ * raycaster kernel has no observable output on an MI355X because CDNA4 has no image hardware:
+ * read_imagef/write_imagef lower to no-ops and the AMD OpenCL runtime refuses clCreateImage
+ * (CL_INVALID_OPERATION); evidence in profiles/r01_reference_kernel_on_gfx950.txt.  Those parts are a
+ * line-by-line restatement (each block cites the reference line it follows) checked by (a) the reference's own
+ * self-check Octree::Validate (src/map/Octree.cpp:329-352), (b) a second, independently written builder in the
+ * product (bit-identical output), (c) Ray::Cast's constant known answer, (d) array-branch == SVO-occupancy
+ * equality on the same grid.  tests/golden/orc_*.npz are regression vectors produced by THIS oracle, not by the
+ * reference.  See DESIGN.md "Oracle and pinning".
  *
  * Float semantics: IEEE-754 binary32, no contraction (build with
  * -ffp-contract=off), correctly rounded / and sqrt.  sin/cos of the camera
@@ -143,6 +143,11 @@ enum {
 #define ORC_FLAG_SHADOW_HIT  4
 #define ORC_FLAG_OOB_EXIT    8
 #define ORC_FLAG_BOUNCE_SHIFT 4   /* 2 bits */
+
+/* view_light (ray_caster_kernel.cl:78-99) on its own, for pinning against the reference's compiled function
+ * (tests/test_reference_pin_gpu.py)                                           */
+void orc_view_light(float out[4], const float in_color[4], const float light[3], const float light_color[4],
+                    const float view[3], const int32_t mask[3]);
 
 void orc_camera_trig(const float cam_dir[2], float trig[4]);
 
