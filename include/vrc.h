@@ -246,6 +246,13 @@ int vrc_octree_save(const char *path, uint32_t dim, const uint64_t *descriptors,
 int vrc_octree_load(const char *path, uint32_t *dim, uint64_t **descriptors, uint64_t *n_descriptors,
                     uint64_t *root_index, uint32_t **lookup, uint64_t **attachments, uint64_t *n_attachments);
 
+/* Streaming upload of a saved tree (a scene is built once, then streamed): reads the file written by
+ * vrc_octree_save in chunks through pinned staging buffers straight into device memory (host memory use is two
+ * chunks, whatever the size of the tree), installs the attachment buffers if the file has them, and sets the
+ * octree_root_index setting like vrc_assign_octree (CLCaster.cpp:113).  *dim receives the map dimension the file
+ * was saved with (the host still owns the octree_dimensions setting).                                            */
+int vrc_assign_octree_file(vrc_caster *h, const char *path, uint32_t *dim);
+
 void vrc_free(void *p);
 
 #ifdef __cplusplus

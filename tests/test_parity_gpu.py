@@ -219,6 +219,32 @@ def test_unnormalised_ray_table(atlas):
     assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
 
 
+def test_streamed_upload_of_a_saved_tree(tmp_path, atlas):
+    """vrc_assign_octree_file: a tree saved with its attachments and streamed from the file into
+    device memory renders the frame the in-memory tree renders; truncated / foreign files are refused."""
+    from test_oracle_cpu import _with_pass_through
+    s = _with_pass_through(scenes.mirror_wall())
+    dim, w, h, md = s["dim"], 160, 120, 3 * s["dim"]
+    o = vrc.Octree.Generate(s["grid"], dim).attach_materials_from_grid(s["grid"])
+    path = str(tmp_path / "scene.svo")
+    o.Save(path)
+    a = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+    assert a.compute()
+    b = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+    assert b.release_octree()
+    assert b.assign_octree_file(path) == dim and b.validate() and b.compute(), b.last_error()
+    assert np.array_equal(a.read_image().view(np.uint32), b.read_image().view(np.uint32))
+    assert np.array_equal(a.read_hits(), b.read_hits()) and a.counters() == b.counters()
+    assert (a.read_hits()[..., 3] == 6).sum() > 0                  # materials came through the file
+    raw = open(path, "rb").read()
+    open(path, "wb").write(raw[: len(raw) // 2])
+    assert b.assign_octree_file(path) == 0 and "truncated" in b.last_error()
+    assert not b.validate()                                         # the half-loaded tree is gone
+    open(path, "wb").write(b"not a tree" * 10)
+    assert b.assign_octree_file(path) == 0 and "VRCSVO01" in b.last_error()
+    assert b.assign_octree_file(str(tmp_path / "missing.svo")) == 0
+
+
 def test_non_cubic_dense_map(atlas):
     """The array branch takes any dx,dy,dz (kernel index x + dx*(y + dz*z), ray_caster_kernel.cl:569)."""
     dx, dy, dz = 24, 16, 16                       # dy == dz keeps the reference's dim.z-as-y-stride quirk in bounds

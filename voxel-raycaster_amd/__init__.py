@@ -96,6 +96,7 @@ SIGNATURES = {
     "vrc_octree_save": (C.c_int, [C.c_char_p, C.c_uint32, _u64p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), _u64p, C.c_uint64]),
     "vrc_octree_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(_u64p), _u64p, _u64p,
                                   C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(_u64p), _u64p]),
+    "vrc_assign_octree_file": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_uint32)]),
     "vrc_free": (None, [C.c_void_p]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
@@ -306,6 +307,12 @@ class CLCaster:
                 self._h, _ptr(oct_.attachment_lookup, C.POINTER(C.c_uint32)), oct_.attachment_lookup.size,
                 _ptr(oct_.attachment_buffer, _u64p), oct_.attachment_buffer.size))
         return True
+
+    def assign_octree_file(self, path: str) -> int:
+        """Extension: stream a tree saved by Octree.Save straight into device memory; returns the map
+        dimension stored in the file, 0 on failure."""
+        dim = C.c_uint32()
+        return int(dim.value) if self._ok(lib.vrc_assign_octree_file(self._h, str(path).encode(), C.byref(dim))) else 0
 
     def release_octree(self) -> bool:
         return self._ok(lib.vrc_release_octree(self._h))

@@ -220,6 +220,64 @@ int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_
     return VRC_OK;
 }
 
+namespace {
+// file -> device through two pinned staging buffers: the read of chunk k+1 overlaps the copy of chunk k
+int stream_to_device(vrc_caster *h, FILE *f, void *dst, size_t bytes, void *stage[2], size_t chunk) {
+    hipEvent_t done[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; i++) HIP_TRY(h, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    int rc = VRC_OK;
+    size_t off = 0;
+    for (int k = 0; off < bytes; k ^= 1) {
+        const size_t n = std::min(chunk, bytes - off);
+        if (hipEventSynchronize(done[k]) != hipSuccess) { rc = fail(h, VRC_ERR_DEVICE, "assign_octree_file: event wait failed"); break; }
+        if (fread(stage[k], 1, n, f) != n) { rc = fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_file: file is truncated"); break; }
+        if (hipMemcpyAsync((char *)dst + off, stage[k], n, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipEventRecord(done[k], h->stream) != hipSuccess) { rc = fail(h, VRC_ERR_DEVICE, "assign_octree_file: upload failed"); break; }
+        off += n;
+    }
+    (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; i++) (void)hipEventDestroy(done[i]);
+    return rc;
+}
+}  // namespace
+
+int vrc_assign_octree_file(vrc_caster *h, const char *path, uint32_t *dim) {
+    if (!h || !path || !dim) return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_file: null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(h, VRC_ERR_NOT_FOUND, "assign_octree_file: cannot open '%s'", path);
+    char magic[8];
+    uint32_t flags = 0;
+    uint64_t root = 0, n = 0, na = 0;
+    const bool header = fread(magic, 1, 8, f) == 8 && memcmp(magic, "VRCSVO01", 8) == 0 && fread(dim, 4, 1, f) == 1 &&
+                        fread(&flags, 4, 1, f) == 1 && fread(&root, 8, 1, f) == 1 && fread(&n, 8, 1, f) == 1 &&
+                        fread(&na, 8, 1, f) == 1 && n > 0 && root < n && *dim >= 2 && (*dim & (*dim - 1)) == 0;
+    if (!header) { fclose(f); return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_file: '%s' is not a VRCSVO01 file", path); }
+    release(h->d_desc); release(h->d_attach_lookup); release(h->d_attach);
+    h->have_octree = false; h->n_desc = 0; h->validated = false;
+    const size_t chunk = (size_t)64 << 20;
+    void *stage[2] = {nullptr, nullptr};
+    int rc = VRC_OK;
+    if (hipHostMalloc(&stage[0], chunk, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&stage[1], chunk, hipHostMallocDefault) != hipSuccess)
+        rc = fail(h, VRC_ERR_OUT_OF_MEMORY, "assign_octree_file: no pinned staging memory");
+    if (rc == VRC_OK && hipMalloc((void **)&h->d_desc, n * sizeof(uint64_t)) != hipSuccess)
+        rc = fail(h, VRC_ERR_OUT_OF_MEMORY, "assign_octree_file: %llu descriptors do not fit in device memory", (unsigned long long)n);
+    if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_desc, n * sizeof(uint64_t), stage, chunk);
+    if (rc == VRC_OK && (flags & 1u)) {
+        if (hipMalloc((void **)&h->d_attach_lookup, n * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void **)&h->d_attach, (na ? na : 1) * sizeof(uint64_t)) != hipSuccess)
+            rc = fail(h, VRC_ERR_OUT_OF_MEMORY, "assign_octree_file: attachment buffers do not fit in device memory");
+        if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_attach_lookup, n * sizeof(uint32_t), stage, chunk);
+        if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_attach, na * sizeof(uint64_t), stage, chunk);
+    }
+    fclose(f);
+    for (int i = 0; i < 2; i++) if (stage[i]) (void)hipHostFree(stage[i]);
+    if (rc != VRC_OK) { release(h->d_desc); release(h->d_attach_lookup); release(h->d_attach); return rc; }
+    h->n_desc = n;
+    h->have_octree = true;
+    return set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)root);   // CLCaster.cpp:113
+}
+
 int vrc_release_octree(vrc_caster *h) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_desc) return fail(h, VRC_ERR_NOT_FOUND, "release_octree: no octree assigned");
