@@ -343,6 +343,30 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
             }
         }
 
+        // ---- phase 2b: one exact step for the lanes that are not deep inside a node.  A lane that has just reached
+        // its safe-run threshold is almost always exactly one iteration from the node face (the threshold is within
+        // n 2^-23 relative of the crossing time), and so is a lane in a freshly entered one-voxel node: one
+        // straight-line iteration with countdowns sends them to the event phase, and the exact loop below only runs
+        // for what is left (lanes near their step cap, t outside the arithmetic range, rare two-step leftovers).
+        if (!kJump && arith_mask && p.single_step != 0 && mode == kStep && !deep) {
+            const float m = fminf(fminf(r.itx, r.ity), r.itz);
+            const float gx = alive_if_zero(r.itx - m, 1.0f);              // :558
+            const float gy = alive_if_zero(r.ity - m, 1.0f);
+            const float gz = alive_if_zero(r.itz - m, 1.0f);
+            r.itx = __builtin_fmaf(r.dtx, gx, r.itx);                     // :559
+            r.ity = __builtin_fmaf(r.dty, gy, r.ity);
+            r.itz = __builtin_fmaf(r.dtz, gz, r.itz);
+            nx -= gx; ny -= gy; nz -= gz;                                 // :560 as countdowns
+            VRC_STAT(w_iters, 1);
+            if ((nx * ny) * nz == 0.0f) {                                 // left the node: bounds test + lookup pending
+                fxf = gx; fyf = gy; fzf = gz;
+                mode = kEvent;                                            // the leaving iteration's :714 follows the lookup
+            } else {
+                r.distance_traveled++;                                    // :714
+                if (r.distance_traveled >= r.max_distance) mode = ended();   // :357
+            }
+        }
+
         // ---- phase 2: ordinary steps (:357-560) for lanes still inside their node.  A lane that is waiting
         // to jump only takes two steps (enough to settle its progressions); the others run to their node face.
         // (skipped when every stepping lane of the wave is still deep inside its node: the next safe run takes them on)

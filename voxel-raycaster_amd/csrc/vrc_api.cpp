@@ -469,8 +469,9 @@ int vrc_compute_async(vrc_caster *h) {
     p.widen_nodes = (int32_t)setting_or(h, "widen_nodes", 1);
     p.arith_mask = (int32_t)setting_or(h, "arith_mask", 1);
     p.safe_run = (int32_t)setting_or(h, "safe_run", 1);
+    p.single_step = (int32_t)setting_or(h, "single_step", 1);
     p.safe_steps = (int32_t)std::min<int64_t>(256, std::max<int64_t>(2, setting_or(h, "safe_steps", 64)));
-    p.exact_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "exact_steps", 8)));
+    p.exact_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "exact_steps", 16)));
     p.xcd_mode = (int32_t)setting_or(h, "xcd_mode", 1);
     p.lds_pad_bytes = (int32_t)std::min<int64_t>(120 * 1024, std::max<int64_t>(0, setting_or(h, "lds_pad_bytes", 0)));
     p.frame = h->d_frame;

@@ -58,7 +58,7 @@ struct RaycastParams {
     float lights[kMaxLights][8];
     int32_t light_count;
     int32_t arith_mask;
-    int32_t safe_run, exact_steps, safe_steps;
+    int32_t safe_run, exact_steps, safe_steps, single_step;
     // frame constants written by frame_setup_kernel: {bias[3], reads} -- the
     // pixel-independent get_oct_vox(camera voxel) of ray_caster_kernel.cl:342-354
     int32_t *frame;
