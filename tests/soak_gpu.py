@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long-running parity soak (not collected by pytest): random camera poses / lights / step caps in the depth-12 bench
-scene and random small scenes, GPU vs oracle, bit for bit.  python tests/soak_gpu.py [seconds] [seed]"""
+scene and random small scenes, GPU vs oracle, bit for bit.  python tests/soak_gpu.py [seconds] [seed] [depth]"""
 import os
 import sys
 import time
@@ -19,7 +19,7 @@ from test_parity_gpu import make_caster  # noqa: E402
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    sc = bench.build_scene(12)
+    sc = bench.build_scene(int(sys.argv[3]) if len(sys.argv) > 3 else 12)
     dim, w, h = sc["dim"], 512, 288
     t0, poses, rows, bad = time.time(), 0, 0, 0
     while time.time() - t0 < budget:
