@@ -28,8 +28,8 @@
 //     stretch by closed forms that reproduce the float recurrence and the
 //     iteration count bit for bit.
 //   * One wavefront = one 8x8 pixel tile (coherent rays walk the same nodes and
-//     L1/L2 lines), 4 tiles per 256-thread block; XCD k (block id mod 8) renders
-//     the tile rows k, k+8, ...: every XCD gets the same sky/ground mix.
+//     L1/L2 lines), 4 tiles per 256-thread block; blocks go to the XCDs round-robin and the block -> tiles
+//     mapping (block_pixel) gives every XCD the same sky/ground mix.
 #include <hip/hip_runtime.h>
 
 #include "exact_jump.hpp"
