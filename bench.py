@@ -288,6 +288,21 @@ def main():
                          "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"], "valu_issue": issue},
         }
         if world == 1 and not args.no_cpu_baseline:
+            # supplementary: two frames in flight (a second caster = second HIP stream + its own buffers) hide the
+            # kernel's ramp-up and tail; the headline `value` above is one frame at a time, like CLCaster::compute
+            c2 = make_caster(sc, W, H, local_rank)
+            for _ in range(2):
+                assert c2.compute(), c2.last_error()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            pairs = max(args.steps // 2, 1)
+            for _ in range(pairs):
+                assert c.compute_async() and c2.compute_async()
+                assert c.sync() and c2.sync()
+            dtp = time.perf_counter() - tp
+            out["two_frames_in_flight"] = {"value": round(rays_per_step * 2 * pairs / dtp / 1e6, 3), "unit": "Mrays/s",
+                                           "ms_per_frame": round(dtp / (2 * pairs) * 1e3, 4)}
+            del c2
             rays, secs, used, cores, nrows, same = cpu_baseline(sc, W, H, gpu_frame=c.read_image())
             out["cpu_baseline"] = {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": used, "kind": "port",
                                    "sample": f"{nrows} of {H} rows of the same frame, oracle/vrc_oracle.c (scalar C, OpenMP over rows), "
