@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
 // SVO branch
 // ---------------------------------------------------------------------------
 #ifndef VRC_MIN_BLOCKS
-#define VRC_MIN_BLOCKS 6            // 256-thread blocks per CU the register budget allows (6 waves per SIMD)
+#define VRC_MIN_BLOCKS (24 / VRC_TILES_PER_BLOCK)   // blocks per CU the register budget allows: 6 waves per SIMD
 #endif
 enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3, kRelight = 4 };
 

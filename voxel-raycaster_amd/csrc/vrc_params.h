@@ -14,7 +14,10 @@ namespace vrc {
 constexpr int kTileW = VRC_TILE_W;    // one wavefront = one kTileW x kTileH pixel tile (8x8)
 constexpr int kTileH = 64 / VRC_TILE_W;
 static_assert((kTileW & (kTileW - 1)) == 0 && kTileW >= 1 && kTileW <= 64, "tile width must be a power of two <= 64");
-constexpr int kTilesPerBlock = 4;     // 256-thread block = 4 horizontally adjacent tiles (32x8 px)
+#ifndef VRC_TILES_PER_BLOCK
+#define VRC_TILES_PER_BLOCK 4
+#endif
+constexpr int kTilesPerBlock = VRC_TILES_PER_BLOCK;   // 256-thread block = 4 horizontally adjacent tiles (32x8 px)
 constexpr int kBlockThreads = 64 * kTilesPerBlock;
 constexpr int kMaxLights = 8;         // light slots (include/LightController.h:95)
 constexpr int kMaxLevels = 24;        // descriptor levels the LDS stack can hold (dim <= 2^24)
