@@ -204,6 +204,37 @@ def test_step_loop_variants_agree(make, atlas):
         assert np.array_equal(frames[0][1], f[1]) and frames[0][2] == f[2]
 
 
+KNOBS = [dict(widen_nodes=0), dict(xcd_mode=0), dict(xcd_mode=2), dict(burst_steps=1, safe_run=0), dict(burst_steps=7, arith_mask=0),
+         dict(shade_threshold=1), dict(shade_threshold=16), dict(exact_steps=1), dict(exact_steps=2, single_step=0),
+         dict(exact_steps=64), dict(lds_pad_bytes=8192), dict(safe_steps=24), dict(safe_steps=100, exact_steps=3),
+         dict(widen_nodes=0, safe_steps=16, shade_threshold=8, xcd_mode=0)]
+
+
+@pytest.mark.parametrize("make", [scenes.floor_pillars, scenes.random_sparse], ids=["floor_pillars", "random_sparse"])
+def test_scheduling_knobs_never_change_the_frame(make, atlas):
+    """widen_nodes, xcd_mode, burst_steps, shade_threshold, exact_steps, safe_steps, lds_pad_bytes only move
+    work around inside the kernel -- frame, hit records and counters stay bit-identical (and equal to the oracle's)."""
+    s = make()
+    dim, w, h = s["dim"], 200, 136
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000).attach_materials_from_grid(s["grid"])
+    md = 3 * dim
+    base = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+    assert base.compute()
+    ref = (base.read_image(), base.read_hits(), base.counters())
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=base._li, atlas=atlas,
+                                    tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                    octree_dim=dim, using_octree=0, max_distance=md, attachment_lookup=o.attachment_lookup,
+                                    attachments=o.attachment_buffer)
+    assert_same(*ref, oimg, ohits, octr)
+    for knobs in KNOBS:
+        c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+        for k, v in knobs.items():
+            assert c.add_to_settings_buffer(k, k.upper(), v)
+        assert c.compute(), (knobs, c.last_error())
+        assert np.array_equal(c.read_image().view(np.uint32), ref[0].view(np.uint32)), knobs
+        assert np.array_equal(c.read_hits(), ref[1]) and c.counters() == ref[2], knobs
+
+
 def test_unnormalised_ray_table(atlas):
     """A host-supplied ray table need not be normalised (vrc_create_viewport_table): delta_t = |1/dir| then falls
     below 1 and the safe run must stand aside (csrc/safe_run.hpp); longer-than-unit and shorter-than-unit rays, SVO."""
