@@ -10,7 +10,7 @@ def main():
     values = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8, 16, 24, 32, 48, 64]
     depth = int(os.environ.get("DEPTH", "12"))
     sc = bench.build_scene(depth)
-    c = bench.make_caster(sc, 1920, 1080, 0)
+    c = bench.make_caster(sc, 1920, 1080, 0, light_count=int(os.environ.get("LIGHTS", "1")))
     for kv in filter(None, os.environ.get("EXTRA", "").split(",")):      # fixed settings: EXTRA="a=1,b=2"
         k, v = kv.split("=")
         c.add_to_settings_buffer(k, k.upper(), int(v))
