@@ -191,7 +191,7 @@ def test_step_loop_variants_agree(make, atlas):
     o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
     md = 20 if dim <= 16 else 3 * dim
     frames = []
-    for arith, safe, safe_steps, single in ((0, 0, 64, 1), (1, 0, 64, 1), (1, 1, 64, 1), (1, 1, 256, 0), (1, 1, 8, 1),
+    for arith, safe, safe_steps, single in ((0, 0, 64, 1), (1, 0, 64, 1), (1, 1, 64, 1), (1, 1, 256, 0), (1, 1, 16, 1), (1, 1, 8, 1),
                                             (1, 1, 2, 1), (1, 1, 64, 0), (1, 0, 64, 0)):
         c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
         assert c.add_to_settings_buffer("single_step", "SINGLE_STEP", single)

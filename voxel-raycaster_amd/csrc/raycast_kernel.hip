@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         // ---- phase 2a: safe run (safe_run.hpp): lanes deep inside an empty node step without countdowns while
         // min(t) is below their threshold T.  All lanes run every trip (a lane whose gate is closed takes empty
         // steps): no exec masking, scalar loop control, kSafeUnroll iterations per loop trip (the vote and the scalar
-        // branch are not free: 2 -> 4 -> 8 iterations per trip measured 3.30 -> 3.11 -> 3.09 ms).
+        // branch are not free: 2 -> 4 -> 8 -> 16 -> 32 iterations per trip measured 3.30 -> 3.11 -> 3.09 -> 3.03 -> 3.14 ms).
         bool deep = false;                                // still far from the node face after the safe run
         if (!kJump && arith_mask && p.safe_run != 0 && safe_cap >= kSafeUnroll) {
             SafeGate gate;
