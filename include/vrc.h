@@ -179,7 +179,8 @@ typedef struct vrc_counters {
     uint64_t map_reads;
     uint64_t steps;
     uint64_t unwritten_pixels;
-    uint64_t reserved;
+    uint64_t watchdog_trips;     /* wavefronts the kernel's round watchdog had to stop.  Always 0; anything else is a
+                                    kernel bug: vrc_get_counters then returns VRC_ERR_DEVICE, the frame is invalid */
 } vrc_counters;
 int vrc_get_counters(vrc_caster *h, vrc_counters *out);
 

@@ -235,6 +235,24 @@ def test_scheduling_knobs_never_change_the_frame(make, atlas):
         assert np.array_equal(c.read_hits(), ref[1]) and c.counters() == ref[2], knobs
 
 
+def test_round_watchdog_reports_instead_of_hanging(atlas):
+    """A wave that would run more rounds than any legal frame needs is stopped and vrc_get_counters reports it
+    (setting watchdog_rounds only exists to provoke this); a normal frame never trips it."""
+    s = scenes.floor_pillars()
+    dim, w, h, md = s["dim"], 128, 96, 3 * s["dim"]
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+    c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+    assert c.compute()
+    good = c.counters()
+    assert good["primary_rays"] == w * h
+    assert c.add_to_settings_buffer("watchdog_rounds", "WATCHDOG_ROUNDS", 2) and c.compute()
+    with pytest.raises(vrc.VrcError):
+        c.counters()
+    assert "watchdog" in c.last_error()
+    assert c.overwrite_setting("watchdog_rounds", 1 << 30) and c.compute()
+    assert c.counters() == good
+
+
 def test_unnormalised_ray_table(atlas):
     """A host-supplied ray table need not be normalised (vrc_create_viewport_table): delta_t = |1/dir| then falls
     below 1 and the safe run must stand aside (csrc/safe_run.hpp); longer-than-unit and shorter-than-unit rays, SVO."""

@@ -44,10 +44,10 @@ _H = C.c_void_p
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "primary_rays", "shadow_rays", "descriptor_reads", "texel_reads", "map_reads", "steps",
-        "unwritten_pixels", "reserved")]
+        "unwritten_pixels", "watchdog_trips")]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "watchdog_trips"}
 
 
 # every symbol include/vrc.h declares, with its signature

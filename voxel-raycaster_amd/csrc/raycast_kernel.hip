@@ -113,7 +113,10 @@ enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3, kRelight = 4 };
 // kJump: also use the closed-form multi-iteration jumps of exact_jump.hpp (opt-in, setting jump_min_run)
 // kMulti: multi-light extension (setting light_count > 1): a finished shadow ray parks the lane in kRelight and
 //         the shade phase restarts it from the first strike toward the next light
-template <bool kJump, bool kMulti>
+// kTuned: the scheduling knobs are at their defaults (vrc_api.cpp), so they are compile-time constants here instead
+//         of kernarg fields held in SGPRs for the whole kernel -- the kernel sits at the SGPR and VGPR limits, and a
+//         single extra live scalar costs several per cent in spills
+template <bool kJump, bool kMulti, bool kTuned>
 __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
     __shared__ unsigned long long block_ctr[kCtrCount];
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         const uint64_t a = p.attachments[p.attach_lookup[node]];
         return (int)(int8_t)(a >> (8 * ((x & 1) | ((y & 1) << 1) | ((z & 1) << 2))));
     };
-    const bool widen = p.widen_nodes != 0;
+    const bool widen = kTuned ? true : p.widen_nodes != 0;
     // park the ray in the empty node of size 2^b around its voxel.  The parent's valid mask is at hand, so the
     // box is widened over empty siblings that lie ahead of the ray: fewer node events, same lookups (a sibling
     // the mask calls empty would have been found empty without any descriptor read).
@@ -238,12 +241,15 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         }
     }
 
-    const int shade_threshold = p.shade_threshold;
+    const bool use_arith = kTuned ? true : p.arith_mask != 0;
+    const bool use_safe = kTuned ? true : p.safe_run != 0;
+    const bool use_single = kTuned ? true : p.single_step != 0;
+    const int shade_threshold = kTuned ? kDefaultShadeThreshold : p.shade_threshold;
     const float jump_min_run = (float)p.jump_min_run;
-    const int exact_cap = (!kJump && p.arith_mask != 0 && p.safe_run != 0) ? p.exact_steps : p.burst_steps;
-    const float safe_limit = safe_t_limit(p.safe_steps);
-    const int safe_cap = p.safe_steps;                   // iterations per safe run (phase 2a)
-    const int burst_cap = p.burst_steps;                 // ordinary steps per round and lane
+    const int safe_cap = kTuned ? kDefaultSafeSteps : p.safe_steps;   // iterations per safe run (phase 2a)
+    const int burst_cap = kTuned ? kDefaultBurstSteps : p.burst_steps;   // ordinary steps per round and lane (compare/select loop)
+    const int exact_cap = (!kJump && use_arith && use_safe) ? (kTuned ? kDefaultExactSteps : p.exact_steps) : burst_cap;
+    const float safe_limit = safe_t_limit(safe_cap);
     JumpCache jcache;
     jump_cache_reset(jcache);
 #ifdef VRC_SCHED_STATS
@@ -256,6 +262,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
 #else
 #define VRC_STAT(var, inc) do { } while (0)
 #endif
+    int rounds_left = p.watchdog_rounds;
     for (;;) {
         // One round = every live lane advances to its next node event: a closed-form jump (long empty
         // stretch) or a burst of ordinary steps (short stretch / not yet in the closed-form regime), then all
@@ -294,14 +301,14 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         // delta_t >= 1/2 per step, so once a lane is safe it stays safe until its ray is restarted (t_unsafe is set
         // again there); a wave with an unsafe stepping lane takes the compare/select loop for this burst.
         if (t_unsafe) t_unsafe = !(t_is_safe(r.itx) && t_is_safe(r.ity) && t_is_safe(r.itz));
-        const bool arith_mask = p.arith_mask != 0 && __ballot(mode == kStep && t_unsafe) == 0ULL;
+        const bool arith_mask = use_arith && __ballot(mode == kStep && t_unsafe) == 0ULL;
 
         // ---- phase 2a: safe run (safe_run.hpp): lanes deep inside an empty node step without countdowns while
         // min(t) is below their threshold T.  All lanes run every trip (a lane whose gate is closed takes empty
         // steps): no exec masking, scalar loop control, kSafeUnroll iterations per loop trip (the vote and the scalar
         // branch are not free: 2 -> 4 -> 8 -> 16 -> 32 iterations per trip measured 3.30 -> 3.11 -> 3.09 -> 3.03 -> 3.14 ms).
         bool deep = false;                                // still far from the node face after the safe run
-        if (!kJump && arith_mask && p.safe_run != 0 && safe_cap >= kSafeUnroll) {
+        if (!kJump && arith_mask && use_safe && safe_cap >= kSafeUnroll) {
             SafeGate gate;
             if (mode == kStep && r.max_distance - r.distance_traveled >= safe_cap) {
                 const float T = fminf(fminf(safe_threshold(r.itx, r.dtx, nx), safe_threshold(r.ity, r.dty, ny)),
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         // n 2^-23 relative of the crossing time), and so is a lane in a freshly entered one-voxel node: one
         // straight-line iteration with countdowns sends them to the event phase, and the exact loop below only runs
         // for what is left (lanes near their step cap, t outside the arithmetic range, rare two-step leftovers).
-        if (!kJump && arith_mask && p.single_step != 0 && mode == kStep && !deep) {
+        if (!kJump && arith_mask && use_single && mode == kStep && !deep) {
             const float m = fminf(fminf(r.itx, r.ity), r.itz);
             const float gx = alive_if_zero(r.itx - m, 1.0f);              // :558
             const float gy = alive_if_zero(r.ity - m, 1.0f);
@@ -438,7 +445,9 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         const unsigned long long ev = __ballot(mode == kEvent);
         const unsigned long long st = __ballot(mode == kStep);
         unsigned long long sh = __ballot(mode == kShade || (kMulti && mode == kRelight));
-        if ((ev | st | sh) == 0ULL) break;
+        // (watchdog: every round advances at least one lane by a step, an event or a hit block, so a wave needs far
+        // fewer rounds than this; stopping a wave that got here keeps the GPU alive and is reported by vrc_get_counters)
+        if ((ev | st | sh) == 0ULL || --rounds_left < 0) break;
 
         // ---- phase 3: node events
         if (ev != 0ULL) {
@@ -506,6 +515,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         }
     }
 
+    if (rounds_left < 0 && (tid & 63) == 0) atomicAdd(&block_ctr[kCtrWatchdog], 1ULL);
     unsigned c_steps = 0, c_tex = 0, c_shadow = 0;
     if (in_image) {
         if (c_primary) {
@@ -583,14 +593,17 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
         const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
         const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t) + (size_t)p.lds_pad_bytes;
         const bool jump = p.jump_min_run < (1 << 24), multi = p.light_count > 1;
-        if (jump && multi)
-            hipLaunchKernelGGL((raycast_svo_kernel<true, true>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
-        else if (jump)
-            hipLaunchKernelGGL((raycast_svo_kernel<true, false>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
-        else if (multi)
-            hipLaunchKernelGGL((raycast_svo_kernel<false, true>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
-        else
-            hipLaunchKernelGGL((raycast_svo_kernel<false, false>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+        const bool tuned = !jump && p.widen_nodes != 0 && p.arith_mask != 0 && p.safe_run != 0 && p.single_step != 0 &&
+                           p.shade_threshold == kDefaultShadeThreshold && p.safe_steps == kDefaultSafeSteps &&
+                           p.exact_steps == kDefaultExactSteps && p.burst_steps == kDefaultBurstSteps;
+#define VRC_LAUNCH(J, M, T) hipLaunchKernelGGL((raycast_svo_kernel<J, M, T>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p)
+        if (jump && multi) VRC_LAUNCH(true, true, false);
+        else if (jump) VRC_LAUNCH(true, false, false);
+        else if (multi && tuned) VRC_LAUNCH(false, true, true);
+        else if (multi) VRC_LAUNCH(false, true, false);
+        else if (tuned) VRC_LAUNCH(false, false, true);
+        else VRC_LAUNCH(false, false, false);
+#undef VRC_LAUNCH
     } else {
         hipLaunchKernelGGL(raycast_array_kernel, dim3(nblocks), dim3(kBlockThreads), 0, stream, p);
     }

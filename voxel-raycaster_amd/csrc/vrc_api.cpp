@@ -463,15 +463,17 @@ int vrc_compute_async(vrc_caster *h) {
     p.max_distance = (int32_t)setting_or(h, "max_distance", 20);
     p.shadow_rays = (int32_t)setting_or(h, "shadow_rays", 1);
     // wave scheduling knobs of the SVO kernel; they never change results
-    p.burst_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "burst_steps", 48)));
-    p.shade_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "shade_threshold", 64)));
+    p.burst_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "burst_steps", vrc::kDefaultBurstSteps)));
+    p.shade_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "shade_threshold", vrc::kDefaultShadeThreshold)));
     p.jump_min_run = (int32_t)std::min<int64_t>(1 << 24, std::max<int64_t>(1, setting_or(h, "jump_min_run", 1 << 24)));
     p.widen_nodes = (int32_t)setting_or(h, "widen_nodes", 1);
     p.arith_mask = (int32_t)setting_or(h, "arith_mask", 1);
+    p.watchdog_rounds = (int32_t)std::min<int64_t>(INT32_MAX, std::max<int64_t>(1, setting_or(h, "watchdog_rounds",
+                                    64LL * ((int64_t)p.max_distance + 64) * (p.light_count + 1))));
     p.safe_run = (int32_t)setting_or(h, "safe_run", 1);
     p.single_step = (int32_t)setting_or(h, "single_step", 1);
-    p.safe_steps = (int32_t)std::min<int64_t>(256, std::max<int64_t>(2, setting_or(h, "safe_steps", 64)));
-    p.exact_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "exact_steps", 16)));
+    p.safe_steps = (int32_t)std::min<int64_t>(256, std::max<int64_t>(2, setting_or(h, "safe_steps", vrc::kDefaultSafeSteps)));
+    p.exact_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "exact_steps", vrc::kDefaultExactSteps)));
     p.xcd_mode = (int32_t)setting_or(h, "xcd_mode", 1);
     p.lds_pad_bytes = (int32_t)std::min<int64_t>(120 * 1024, std::max<int64_t>(0, setting_or(h, "lds_pad_bytes", 0)));
     p.frame = h->d_frame;
@@ -584,7 +586,11 @@ int vrc_get_counters(vrc_caster *h, vrc_counters *out) {
     out->descriptor_reads = c[vrc::kCtrDesc]; out->texel_reads = c[vrc::kCtrTex];
     out->map_reads = c[vrc::kCtrMap]; out->steps = c[vrc::kCtrSteps];
     out->unwritten_pixels = c[vrc::kCtrUnwritten];
+    out->watchdog_trips = c[vrc::kCtrWatchdog];
     for (int i = 0; i < 8; i++) h->sched_stats[i] = c[8 + i];
+    if (out->watchdog_trips)
+        return fail(h, VRC_ERR_DEVICE, "the kernel's round watchdog stopped %llu wavefronts: the frame is invalid",
+                    (unsigned long long)out->watchdog_trips);
     return VRC_OK;
 }
 

@@ -19,6 +19,8 @@ static_assert((kTileW & (kTileW - 1)) == 0 && kTileW >= 1 && kTileW <= 64, "tile
 #endif
 constexpr int kTilesPerBlock = VRC_TILES_PER_BLOCK;   // 256-thread block = 4 horizontally adjacent tiles (32x8 px)
 constexpr int kBlockThreads = 64 * kTilesPerBlock;
+// defaults of the scheduling knobs (settings of the same names; the tuned kernel instances have them compiled in)
+constexpr int kDefaultBurstSteps = 48, kDefaultShadeThreshold = 64, kDefaultSafeSteps = 64, kDefaultExactSteps = 16;
 constexpr int kMaxLights = 8;         // light slots (include/LightController.h:95)
 constexpr int kMaxLevels = 24;        // descriptor levels the LDS stack can hold (dim <= 2^24)
 
@@ -27,7 +29,7 @@ constexpr int kFlagWritten = 1, kFlagShadowCast = 2, kFlagShadowHit = 4, kFlagOo
 
 // counters[] slots (device, uint64)
 enum CounterSlot {
-    kCtrPrimary = 0, kCtrShadow, kCtrDesc, kCtrTex, kCtrMap, kCtrSteps, kCtrUnwritten,
+    kCtrPrimary = 0, kCtrShadow, kCtrDesc, kCtrTex, kCtrMap, kCtrSteps, kCtrUnwritten, kCtrWatchdog,
     // wave-scheduler statistics of the SVO kernel (one count per wave, not per lane)
     kCtrWaveIters = 8, kCtrBursts, kCtrEventPasses, kCtrEventLanes, kCtrShadePasses, kCtrShadeLanes, kCtrCount = 16
 };
@@ -61,6 +63,7 @@ struct RaycastParams {
     float lights[kMaxLights][8];
     int32_t light_count;
     int32_t arith_mask;
+    int32_t watchdog_rounds;          // rounds a wave may take before the watchdog stops it
     int32_t safe_run, exact_steps, safe_steps, single_step;
     // frame constants written by frame_setup_kernel: {bias[3], reads} -- the
     // pixel-independent get_oct_vox(camera voxel) of ray_caster_kernel.cl:342-354
