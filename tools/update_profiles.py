@@ -17,13 +17,13 @@ old = open(os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")).read()
 history = old[old.index("\n# the same counters for earlier kernels"):] if "# the same counters for earlier kernels" in old else ""
 open(os.path.join(ROOT, "profiles", "r01_pmc_summary.txt"), "w").write(
     "# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline\n"
-    f"# separate passes (tools/gpu_pmc.sh); per-dispatch averages of raycast_svo_kernel<false, false> (tools/pmc_summary.py), {label}\n"
+    f"# separate passes (tools/gpu_pmc.sh); per-dispatch averages of raycast_svo_kernel<false, false, true> (tools/pmc_summary.py), {label}\n"
     f"# VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) = {util:.2f} (lanes that take empty steps in a safe run count as active)\n"
     + pm + history)
 hbm = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
 json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
            "correction": "gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md HBM section: rocprofv3 reports half of wide coalesced reads; applied to all reads = upper bound), WRITE_SIZE as reported (99.5 MB float4 frame + hit records, the rest is the kernel's register-spill scratch)",
-           "source": "profiles/r01_pmc_summary.txt (separate --pmc passes, kernel raycast_svo_kernel<false, false>, headline workload)",
+           "source": "profiles/r01_pmc_summary.txt (separate --pmc passes, kernel raycast_svo_kernel<false, false, true>, headline workload)",
            "valu_insts_per_launch": int(vals["SQ_INSTS_VALU"]), "valu_source": "SQ_INSTS_VALU, profiles/r01_pmc_summary.txt"},
           open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
 b = json.loads(bench)
