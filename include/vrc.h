@@ -229,6 +229,14 @@ int vrc_scene_shell_terrain(uint32_t depth, uint64_t seed, int32_t thickness,
                             int32_t *height);
 /* Dense twin of the above for depth <= 9 (fills char[dim^3] with material 5). */
 int vrc_scene_shell_terrain_dense(uint32_t depth, uint64_t seed, int32_t thickness, int8_t *grid);
+/* Map::GenerateHeightBitmap (src/map/Map.cpp:144-262): the reference's diamond-square height field
+ * (std::mt19937 default seed, offsets in +-h with h = 20 halved per level, wrap-around sampling :266-272), whose
+ * output the reference drops in the empty Map::ApplyHeightmap (:140-142).  height: uint8[dim*dim] =
+ * clamp(value, 0, dim) like :241; corner_seed is the reference's `rand() % 10 + 55` (:160; 58 with an unseeded glibc).
+ * grid (optional, int8[dim^3], x + dim*(y + dim*z)): what ApplyHeightmap was meant to do -- material 5 at and
+ * below the height of each column, 0 above (our definition; the reference has none).                            */
+int vrc_scene_diamond_square(uint32_t dim, double corner_seed, uint8_t *height, int8_t *grid);
+
 /* Synthetic 256x256-style atlas: texel = hash(x,y) & 0xFFFFFF, alpha 255.    */
 int vrc_scene_atlas(int32_t width, int32_t height, uint8_t *rgba8);
 

@@ -126,6 +126,24 @@ def test_sparse_terrain_builder_equals_dense_builder(depth):
     assert height.min() >= dim // 4 and height.max() < 3 * dim // 4 + 1
 
 
+def test_diamond_square_heightmap_scene():
+    """Map::GenerateHeightBitmap restated (src/map/Map.cpp:144-262, SURVEY 8f-4): deterministic, seeded corners,
+    heights clamped like :248; the voxel fill (ApplyHeightmap is empty in the reference) gives a grid both builders
+    turn into the same valid tree."""
+    h1, g1 = vrc.diamond_square(64)
+    h2, _ = vrc.diamond_square(64, want_grid=False)
+    assert np.array_equal(h1, h2) and h1[0, 0] == 58 and 0 <= int(h1.min()) and int(h1.max()) <= 64
+    assert len(np.unique(h1)) > 20                                   # a terrain, not a plane
+    g = g1.reshape(64, 64, 64)
+    assert ((g == 5).sum(axis=0) == h1.astype(np.int64) + 1).all()   # material 5 at and below the column height
+    h3, _ = vrc.diamond_square(64, corner_seed=30.0, want_grid=False)
+    assert not np.array_equal(h1, h3)
+    o = vrc.Octree.Generate(g1, 64, buffer_size=100000, strict_reference=True)
+    buf, root = orc.octree_generate(g1, 64)
+    assert root == o.root_index and np.array_equal(buf, o.descriptor_buffer)
+    assert orc.octree_validate(g1, 64, buf, root) == 0
+
+
 def test_octree_save_load_roundtrip(tmp_path):
     rng = np.random.default_rng(21)
     g = (rng.random(32 ** 3) < 0.1).astype(np.int8) * 5

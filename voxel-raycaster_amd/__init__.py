@@ -97,6 +97,7 @@ SIGNATURES = {
     "vrc_octree_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(_u64p), _u64p, _u64p,
                                   C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(_u64p), _u64p]),
     "vrc_assign_octree_file": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_uint32)]),
+    "vrc_scene_diamond_square": (C.c_int, [C.c_uint32, C.c_double, _u8p, _i8p]),
     "vrc_free": (None, [C.c_void_p]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
@@ -231,6 +232,17 @@ def shell_terrain_dense(depth: int, seed: int = 1, thickness: int = 2) -> np.nda
     if rc != 0:
         raise VrcError(f"vrc_scene_shell_terrain_dense: {STATUS.get(rc, rc)}")
     return grid
+
+
+def diamond_square(dim: int, corner_seed: float = 58.0, want_grid: bool = True):
+    """Map::GenerateHeightBitmap (src/map/Map.cpp:144-262) + the voxel fill ApplyHeightmap never got (SURVEY 8f-4).
+    Returns (height uint8[dim, dim], grid int8[dim^3] or None)."""
+    height = np.zeros((dim, dim), dtype=np.uint8)
+    grid = np.zeros(dim ** 3, dtype=np.int8) if want_grid else None
+    rc = lib.vrc_scene_diamond_square(dim, corner_seed, _ptr(height, _u8p), _ptr(grid, _i8p) if want_grid else None)
+    if rc != 0:
+        raise VrcError(f"vrc_scene_diamond_square: {STATUS.get(rc, rc)}")
+    return height, grid
 
 
 def synthetic_atlas(width: int = 256, height: int = 256) -> np.ndarray:

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <vector>
 
 #include "../../include/vrc.h"
@@ -374,6 +375,44 @@ int vrc_scene_shell_terrain_attachments(uint32_t depth, uint64_t seed, uint32_t 
         return (h % mirror_period) == 0 ? 6 : 5;
     };
     return build_attachments(descriptors, n_descriptors, root_index, 1u << depth, mat, lookup, attachments, n_attachments);
+}
+
+int vrc_scene_diamond_square(uint32_t dim, double corner_seed, uint8_t *height, int8_t *grid) {
+    if (!is_pow2(dim) || dim > 4096 || !height) return VRC_ERR_INVALID_ARGUMENT;
+    const int n = (int)dim, size = n + 1;                     // Map.cpp:157 DATA_SIZE (samples wrap, :266-272)
+    std::vector<double> hm((size_t)n * n, 0.0);
+    auto at = [&](int x, int y) -> double & { return hm[(size_t)(x & (n - 1)) + (size_t)(y & (n - 1)) * n]; };
+    std::mt19937 gen;                                          // :146 default seed
+    std::uniform_real_distribution<double> dis(-1.0, 1.0);    // :147
+    auto f_rand = [&]() { return dis(gen); };
+    at(0, 0) = corner_seed; at(0, n) = corner_seed; at(n, 0) = corner_seed; at(n, n) = corner_seed;   // :163-166
+    double h = 20.0;                                           // :168
+    for (int side = size - 1; side >= 2; side /= 2, h /= 2.0) {   // :172-180
+        const int half = side / 2;
+        for (int x = 0; x < size - 1; x += side)               // squares :187-203
+            for (int y = 0; y < size - 1; y += side) {
+                const double avg = (at(x, y) + at(x + side, y) + at(x, y + side) + at(x + side, y + side)) / 4.0;
+                at(x + half, y + half) = avg + (f_rand() * 2 * h) - h;
+            }
+        for (int x = 0; x < size - 1; x += half)               // diamonds :210-241
+            for (int y = (x + half) % side; y < size - 1; y += side) {
+                double avg = (at((x - half + size) % size, y) + at((x + half) % size, y) + at(x, (y + half) % size) +
+                              at(x, (y - half + size) % size)) / 4.0;
+                avg = avg + (f_rand() * 2 * h) - h;
+                at(x, y) = avg;
+                if (x == 0) at(size - 1, y) = avg;
+                if (y == 0) at(x, size - 1) = avg;
+            }
+    }
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++)                            // :248 clamp to [0, dimensions.z]
+            height[(size_t)x + (size_t)y * n] = (uint8_t)std::min(std::max(hm[(size_t)x + (size_t)y * n], 0.0), (double)std::min(n, 255));
+    if (grid)
+        for (int z = 0; z < n; z++)
+            for (int y = 0; y < n; y++)
+                for (int x = 0; x < n; x++)
+                    grid[(size_t)x + (size_t)n * ((size_t)y + (size_t)n * z)] = z <= (int)height[(size_t)x + (size_t)y * n] ? 5 : 0;
+    return VRC_OK;
 }
 
 int vrc_scene_atlas(int32_t width, int32_t height, uint8_t *rgba8) {
