@@ -235,6 +235,25 @@ def test_scheduling_knobs_never_change_the_frame(make, atlas):
         assert np.array_equal(c.read_hits(), ref[1]) and c.counters() == ref[2], knobs
 
 
+@pytest.mark.parametrize("using_octree", [1, 0], ids=["array", "svo"])
+def test_diamond_square_terrain_scene(using_octree, atlas):
+    """The reference's own terrain generator (Map::GenerateHeightBitmap, SURVEY 8f-4) as a scene: 128^3, camera over
+    the hills, light high above -- both kernels bit-exact vs the oracle."""
+    dim, w, h, md = 128, 192, 128, 3 * 128
+    height, grid = vrc.diamond_square(dim)
+    o = vrc.Octree.Generate(grid, dim)
+    cam_pos = (dim * 0.5 + 0.3, dim * 0.1 + 0.2, 40.3)
+    cam_dir = (1.67, 1.5708)
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, dim * 0.3, dim * 0.6, dim * 0.95, -1, -1, -1.5]], dtype=np.float32)
+    c = make_caster(o, dim, using_octree, cam_dir, cam_pos, lights, atlas, w, h, md, grid=grid)
+    assert c.compute(), c.last_error()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas,
+                                    tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                    octree_dim=dim, using_octree=using_octree, grid=grid, max_distance=md)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+    assert (ohits[..., 3] == 5).mean() > 0.3 and octr["shadow_rays"] > 0.3 * w * h
+
+
 def test_round_watchdog_reports_instead_of_hanging(atlas):
     """A wave that would run more rounds than any legal frame needs is stopped and vrc_get_counters reports it
     (setting watchdog_rounds only exists to provoke this); a normal frame never trips it."""
