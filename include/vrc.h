@@ -126,7 +126,8 @@ int vrc_assign_lights(vrc_caster *h, const float *packed, const int32_t *light_c
  *   using_octree       (OCTENABLED)        0 => occupancy from the SVO, != 0 => dense map
  *   octree_root_index  (OCTREE_ROOT_INDEX) set by vrc_assign_octree
  * extensions (defaults reproduce the reference):
- *   max_distance (20)  shadow_rays (1)  light_count (1, see vrc_assign_lights) */
+ *   max_distance (20)  shadow_rays (1)  light_count (1, see vrc_assign_lights)
+ *   octree_bias (1: the :353-354 term as in the reference; 0: without it)    */
 int vrc_setting_add(vrc_caster *h, const char *name, const char *define, int64_t value);
 /* CLCaster::overwrite_setting (CLCaster.cpp:1087-1109) */
 int vrc_setting_set(vrc_caster *h, const char *name, int64_t value);

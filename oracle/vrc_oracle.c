@@ -699,7 +699,7 @@ void orc_raycast(const orc_scene *s, int32_t y0, int32_t y1, float *image, int32
     orc_get_oct_vox(cam_voxel, s->descriptors, (uint64_t)s->octree_root_index,
                     (int32_t)s->octree_dimensions, &ts);
     for (int a = 0; a < 3; a++)
-        bias[a] = (ts.sub_oct_pos[a] - cam_voxel[a]) * ts.resolution / 2;
+        bias[a] = s->no_bias ? 0 : (ts.sub_oct_pos[a] - cam_voxel[a]) * ts.resolution / 2;
 
     const int W = s->resolution[0];
     orc_counters total;

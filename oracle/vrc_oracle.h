@@ -114,6 +114,7 @@ typedef struct {
     /* extensions; the defaults reproduce the reference */
     int32_t         max_distance;        /* ray_caster_kernel.cl:326 => 20 */
     int32_t         shadow_rays;         /* 1; 0 = shade the primary hit and stop */
+    int32_t         no_bias;             /* 0: the reference (:353-354); 1: extension, drop the octree bias term */
     int32_t         active_lights;       /* <= 1: light 0 only (the reference); n: the first n lights, each
                                             from the first strike (see light_from_strike)       */
     float           cam_trig[4];         /* sin(dir.x) cos(dir.x) sin(dir.y) cos(dir.y) */

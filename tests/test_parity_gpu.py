@@ -254,6 +254,26 @@ def test_diamond_square_terrain_scene(using_octree, atlas):
     assert (ohits[..., 3] == 5).mean() > 0.3 and octr["shadow_rays"] > 0.3 * w * h
 
 
+@pytest.mark.parametrize("using_octree", [1, 0], ids=["array", "svo"])
+def test_octree_bias_can_be_switched_off(using_octree, atlas):
+    """The reference adds (sub_oct_pos - voxel) * resolution / 2 to intersection_t (:353-354), which shears the
+    picture whenever the camera is in an empty node whose corner is not the camera voxel.  Setting octree_bias = 0
+    (extension) drops it; both ways equal the oracle, and they differ from each other in this scene."""
+    s = scenes.open_sky()
+    dim, w, h, md = s["dim"], 128, 96, 3 * s["dim"]
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+    frames = []
+    for bias in (1, 0):
+        c = make_caster(o, dim, using_octree, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md, grid=s["grid"])
+        assert c.add_to_settings_buffer("octree_bias", "OCTREE_BIAS", bias) and c.compute(), c.last_error()
+        oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=c._li, atlas=atlas,
+                                        tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                        octree_dim=dim, using_octree=using_octree, grid=s["grid"], max_distance=md, no_bias=1 - bias)
+        assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+        frames.append(c.read_hits())
+    assert not np.array_equal(frames[0], frames[1])
+
+
 def test_round_watchdog_reports_instead_of_hanging(atlas):
     """A wave that would run more rounds than any legal frame needs is stopped and vrc_get_counters reports it
     (setting watchdog_rounds only exists to provoke this); a normal frame never trips it."""

@@ -577,7 +577,9 @@ __global__ void frame_setup_kernel(const RaycastParams p) {
         d = p.descriptors[index];
         reads++;
     }
-    for (int a = 0; a < 3; a++) p.frame[a] = (corner[a] - pos[a]) * res / 2;
+    // setting octree_bias = 0 (extension) drops the term: the reference's bias shears the picture whenever the camera
+    // sits in an empty node whose corner is not the camera voxel
+    for (int a = 0; a < 3; a++) p.frame[a] = p.octree_bias ? (corner[a] - pos[a]) * res / 2 : 0;
     p.frame[3] = reads;
 }
 

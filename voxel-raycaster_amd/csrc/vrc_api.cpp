@@ -467,6 +467,7 @@ int vrc_compute_async(vrc_caster *h) {
     p.shade_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "shade_threshold", vrc::kDefaultShadeThreshold)));
     p.jump_min_run = (int32_t)std::min<int64_t>(1 << 24, std::max<int64_t>(1, setting_or(h, "jump_min_run", 1 << 24)));
     p.widen_nodes = (int32_t)setting_or(h, "widen_nodes", 1);
+    p.octree_bias = (int32_t)setting_or(h, "octree_bias", 1);
     p.arith_mask = (int32_t)setting_or(h, "arith_mask", 1);
     p.watchdog_rounds = (int32_t)std::min<int64_t>(INT32_MAX, std::max<int64_t>(1, setting_or(h, "watchdog_rounds",
                                     64LL * ((int64_t)p.max_distance + 64) * (p.light_count + 1))));

@@ -62,6 +62,7 @@ struct RaycastParams {
     // only) is the reference; more is the multi-light extension (setting "light_count")
     float lights[kMaxLights][8];
     int32_t light_count;
+    int32_t octree_bias;              // 1: the reference's (sub_oct_pos - voxel) * resolution / 2 term (:353-354); 0: none
     int32_t arith_mask;
     int32_t watchdog_rounds;          // rounds a wave may take before the watchdog stops it
     int32_t safe_run, exact_steps, safe_steps, single_step;
