@@ -477,6 +477,25 @@ def test_baseline_configs_sampled_rows(depth, w, h):
         assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
 
 
+def test_8k_frame_sampled_rows():
+    """BASELINE configs[4]'s frame size on the depth-12 scene: 7680x4320 (33 M pixels, 129 600 blocks, 1.6 GB of frame +
+    hit records): sampled rows bit-exact vs the oracle."""
+    sc = _bench_scene(12)
+    dim, w, h = sc["dim"], 7680, 4320
+    c = make_caster(sc["octree"], dim, 0, sc["cam_dir"], sc["cam_pos"], sc["lights"], sc["atlas"], w, h, 3 * dim)
+    assert c.compute(), c.last_error()
+    ctr = c.counters()
+    assert ctr["primary_rays"] == w * h
+    img, hits = c.read_image(), c.read_hits()
+    for y0 in (3, 2161, 4316):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=c._li,
+                                     atlas=sc["atlas"], tile_dim=(16, 16), descriptors=sc["octree"].descriptor_buffer,
+                                     root_index=sc["octree"].root_index, octree_dim=dim, using_octree=0,
+                                     max_distance=3 * dim, rows=(y0, y0 + 1), threads=16)
+        assert np.array_equal(hits[y0], ohits[y0])
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+
+
 @pytest.mark.parametrize("w,h,n", [(3840, 2160, 2), (1920, 1080, 4)], ids=["C4-4K-2lights", "d12-1080p-4lights"])
 def test_multi_light_baseline_geometry_sampled_rows(w, h, n):
     """BASELINE configs[3] geometry on one GPU (depth-12 SVO, 3840x2160, 2 lights) and configs[4]'s light count on
