@@ -274,6 +274,34 @@ def test_octree_bias_can_be_switched_off(using_octree, atlas):
     assert not np.array_equal(frames[0], frames[1])
 
 
+def test_lifecycle_release_and_device_image(atlas):
+    """release_* put the handle back into 'not ready' (validate/compute fail, nothing crashes), re-assigning makes it
+    whole again with the same frame; vrc_device_image hands out the float4 frame in HBM for same-GPU consumers."""
+    import torch
+    s = scenes.floor_pillars()
+    dim, w, h, md = s["dim"], 128, 96, 3 * s["dim"]
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+    c = make_caster(o, dim, 1, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md, grid=s["grid"])
+    assert c.compute()
+    ref = c.read_image().copy()
+    ptr, nbytes = c.device_image()
+    assert nbytes == w * h * 16
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    host = np.zeros((h, w, 4), dtype=np.float32)
+    assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 2) == 0   # device -> host
+    assert np.array_equal(host.view(np.uint32), ref.view(np.uint32))
+    for release, restore in ((c.release_camera, lambda: c.assign_camera(np.array(s["cam_dir"], np.float32), np.array(s["cam_pos"], np.float32))),
+                             (c.release_viewport, lambda: c.create_viewport(w, h)),
+                             (c.release_octree, lambda: c.assign_octree(o)),
+                             (c.release_map, lambda: c.assign_map(s["grid"], (dim, dim, dim)))):
+        assert release()
+        assert not c.validate() and not c.compute()
+        keep = restore()                                                        # arrays must outlive the handle's use
+        assert keep and c.validate(), c.last_error()
+        assert c.compute() and np.array_equal(c.read_image().view(np.uint32), ref.view(np.uint32))
+
+
 def test_round_watchdog_reports_instead_of_hanging(atlas):
     """A wave that would run more rounds than any legal frame needs is stopped and vrc_get_counters reports it
     (setting watchdog_rounds only exists to provoke this); a normal frame never trips it."""

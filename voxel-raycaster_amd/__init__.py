@@ -361,6 +361,13 @@ class CLCaster:
     def release_viewport(self) -> bool:
         return self._ok(lib.vrc_release_viewport(self._h))
 
+    def device_image(self):
+        """(device pointer, bytes) of the float4 frame in HBM, for consumers on the same GPU (vrc_device_image)."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        if not self._ok(lib.vrc_device_image(self._h, C.byref(ptr), C.byref(n))):
+            raise VrcError(self.last_error())
+        return ptr.value, n.value
+
     def create_texture_atlas(self, rgba8: np.ndarray, tile_dim) -> bool:
         a = np.ascontiguousarray(rgba8, dtype=np.uint8)
         hgt, wid = a.shape[0], a.shape[1]
