@@ -302,6 +302,29 @@ def test_lifecycle_release_and_device_image(atlas):
         assert c.compute() and np.array_equal(c.read_image().view(np.uint32), ref.view(np.uint32))
 
 
+def test_async_frames_timing_and_settings_queries(atlas):
+    """vrc_compute_async / vrc_sync queue frames on the handle's stream (live camera pointers are read at enqueue time),
+    vrc_timing_* reports one hipEvent-timed launch per frame, settings can be read back, and the profiling counters of
+    the product build are zero (they exist only in the -DVRC_SCHED_STATS build)."""
+    s = scenes.random_sparse()
+    dim, w, h, md = s["dim"], 160, 120, 3 * s["dim"]
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+    c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, md)
+    assert c.get_setting("max_distance") == md and c.get_setting("using_octree") == 0
+    assert c.get_setting("octree_root_index") == o.root_index and c.get_setting("no_such_setting") is None
+    assert c.timing_reset()
+    for _ in range(5):
+        assert c.compute_async()
+    assert c.sync()
+    n, ms = c.timing()
+    assert n == 5 and 0.0 < ms < 1000.0
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=c._li, atlas=atlas,
+                                    tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                    octree_dim=dim, using_octree=0, max_distance=md)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+    assert all(v == 0 for v in c.scheduler_stats().values())
+
+
 def test_round_watchdog_reports_instead_of_hanging(atlas):
     """A wave that would run more rounds than any legal frame needs is stopped and vrc_get_counters reports it
     (setting watchdog_rounds only exists to provoke this); a normal frame never trips it."""
