@@ -32,6 +32,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+# VALU issue peak: 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles per SIMD, 2.4 GHz (MI355X_MICROARCH.md)
+VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
+KERNEL_SOURCES = ("raycast_kernel.hip", "raycast_common.hpp", "safe_run.hpp", "exact_jump.hpp", "vrc_params.h")
+
+
+def kernel_source_hash() -> str:
+    """Identifies the kernel a committed PMC measurement belongs to (profiles/traffic_latest.json carries it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "voxel-raycaster_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 # --------------------------------------------------------------------------- scene
@@ -80,17 +92,21 @@ def supersampled_table(width: int, height: int, n: int) -> np.ndarray:
     return t
 
 
-def make_caster(sc, width, height, device, table=None, shadow_rays=1, light_count=1):
+def make_caster(sc, width, height, device, table=None, shadow_rays=1, light_count=1, row_slice=None, octree_file=None,
+                hit_records=1):
     import voxel_raycaster_amd as vrc
     c = vrc.CLCaster()
     if not c.init(device):
         raise RuntimeError("vrc_create failed: no MI355X visible (there is no CPU fallback)")
+    if row_slice is not None and not c.set_row_slice(*row_slice):      # (rank, world, band_rows): buffers hold 1/world of the frame
+        raise RuntimeError("set_row_slice failed: " + c.last_error())
     ok = (c.add_to_settings_buffer("octree_dimensions", "OCTDIM", sc["dim"])
           and c.add_to_settings_buffer("using_octree", "OCTENABLED", 0)
           and c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", 3 * sc["dim"])
           and c.add_to_settings_buffer("shadow_rays", "SHADOW_RAYS", shadow_rays)
           and c.add_to_settings_buffer("light_count", "LIGHT_COUNT", light_count)
-          and c.assign_octree(sc["octree"])
+          and c.add_to_settings_buffer("hit_records", "HIT_RECORDS", hit_records)
+          and (c.assign_octree(sc["octree"]) if octree_file is None else c.assign_octree_file(octree_file) == sc["dim"])
           and c.assign_camera(sc["cam_dir"], sc["cam_pos"])
           and (c.create_viewport(width, height) if table is None else c.create_viewport_table(table))
           and c.assign_lights(sc["lights"])
@@ -179,6 +195,27 @@ def ray_cpp_baseline():
             "workload": "configs[0]: 256^3 dense grid, 640x480, Ray::Cast restated (600-step cap)", "dda_steps": steps}
 
 
+def shared_scene(depth, rank, world, tag):
+    """The scene is built ONCE: rank 0 builds it and saves the tree (vrc_octree_save); the other ranks stream the file
+    straight into their own HBM (vrc_assign_octree_file) and never hold a host copy.  Returns (scene dict, file or None)."""
+    import torch.distributed as dist
+    import voxel_raycaster_amd as vrc
+    if world == 1:
+        return build_scene(depth), None
+    path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"vrc_bench_{tag}.svo")
+    meta = [None]
+    if rank == 0:
+        sc = build_scene(depth)
+        sc["octree"].Save(path)
+        meta[0] = {k: sc[k] for k in ("depth", "dim", "cam_pos", "cam_dir", "lights")}
+        meta[0]["n_desc"] = int(sc["octree"].descriptor_buffer.size)
+    dist.broadcast_object_list(meta, src=0)
+    if rank != 0:
+        sc = dict(meta[0], octree=None, atlas=vrc.synthetic_atlas(256, 256))
+    sc["n_desc"] = meta[0]["n_desc"]
+    return sc, path
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,6 +225,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-build", action="store_true",
+                    help="never spawn a compiler: fail if a library is stale (required under rocprofv3: the profiler's preloaded "
+                         "library must not be inherited by child processes of a GPU-initialised program)")
     ap.add_argument("--pmc-traffic", type=str, default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="JSON file with the rocprofv3 PMC measurement of HBM bytes per launch (see DESIGN.md 7)")
     args = ap.parse_args()
@@ -199,12 +239,21 @@ def main():
     if world != n and world != 1:
         raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
 
+    # build BEFORE anything touches the GPU (a GPU-initialised process must not spawn compilers); under torchrun the
+    # local rank 0 builds, the others wait for its marker file
+    import __graft_entry__ as graft
+    if args.no_build:
+        if graft.stale():
+            raise SystemExit("bench.py --no-build: libvrc.so / the oracle are stale; run `python __graft_entry__.py` first")
+    elif local_rank == 0:
+        graft.build()
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
     # test hook (tests/ and rehearsals on a 1-GPU box only): let several ranks share GPU 0 over gloo so that the
-    # N>1 code path -- supersampled ray table, row tiling, SUM/MAX reductions -- can be exercised without 8 GPUs
+    # N>1 code path -- supersampled ray table, row slices, SUM/MAX reductions -- can be exercised without 8 GPUs
     rehearsal = os.environ.get("VRC_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
@@ -213,19 +262,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL: barrier + scalar reductions only
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
+        dist.barrier()                     # rank 0's build is finished before any other rank imports the library
+    import voxel_raycaster_amd  # noqa: F401  (fails loudly if the HIP library is missing)
 
-    import __graft_entry__ as graft
-    if rank == 0:
-        graft.build()
-    if world > 1:
-        dist.barrier()
-
-    sc = build_scene(args.depth)
+    sc, tree_file = shared_scene(args.depth, rank, world, os.environ.get("MASTER_PORT", "0"))
     W, H = args.width, args.height
     full_h = H * world
     table = None if world == 1 else supersampled_table(W, H, world)
-    c = make_caster(sc, W, full_h, local_rank, table=table)
-    c.set_row_tiling(rank, world, 8)
+    # N > 1: each rank holds only its row bands of the ray table / frame / hit records (1/N of the frame)
+    c = make_caster(sc, W, full_h, local_rank, table=table, row_slice=None if world == 1 else (rank, world, 8),
+                    octree_file=None if rank == 0 else tree_file)
+    del table
+    if world > 1:
+        dist.barrier()
+        if rank == 0:
+            os.remove(tree_file)
 
     for _ in range(args.warmup):
         if not c.compute():
@@ -257,18 +308,26 @@ def main():
         bytes_per_launch = algorithmic_bytes(ctr, local_pixels, written)
         avg_kernel_s = kernel_ms / max(n_launch, 1) / 1e3
         achieved = bytes_per_launch / avg_kernel_s / 1e9
-        traffic = None        # HBM bytes per launch from the committed PMC passes (N=1 headline workload only)
+        # HBM bytes and VALU instructions per launch come from rocprofv3 PMC passes (tools/gpu_pmc.sh: counters cannot be
+        # read inside this process).  The committed measurement is stamped with the hash of the kernel sources it was
+        # taken on; a different kernel => null, never a stale number.
+        traffic, issue, pmc_note = None, None, "no PMC measurement for this workload"
         if world == 1 and args.depth == 12 and (W, H) == (1920, 1080) and args.pmc_traffic and os.path.exists(args.pmc_traffic):
-            traffic = json.load(open(args.pmc_traffic)).get("hbm_bytes_per_launch")
-        # what actually bounds the kernel: VALU issue.  The float recurrence of ray_caster_kernel.cl:558-559 (min, three
-        # masks, three fused updates = 10 wave64 instructions per 64 lane steps) is the floor of any bit-exact
-        # stepping kernel; valu_floor_frac = that floor / the VALU instructions the kernel issues (PMC).
-        issue = None
-        if traffic is not None:
-            valu = json.load(open(args.pmc_traffic)).get("valu_insts_per_launch")
-            if valu:
-                floor = ctr["steps"] / 64.0 * 10.0
-                issue = {"valu_insts_per_launch": int(valu), "floor_insts": int(floor), "valu_floor_frac": round(floor / valu, 4)}
+            pmc = json.load(open(args.pmc_traffic))
+            if pmc.get("kernel_source_hash") == kernel_source_hash():
+                traffic = pmc.get("hbm_bytes_per_launch")
+                pmc_note = pmc.get("source")
+                valu = pmc.get("valu_insts_per_launch")
+                if valu:
+                    # the float recurrence of ray_caster_kernel.cl:558-559 (min, three masks, three fused updates = 10 wave64
+                    # instructions per 64 lane steps) is the floor of any bit-exact stepping kernel
+                    floor = ctr["steps"] / 64.0 * 10.0
+                    rate = valu / avg_kernel_s / 1e9
+                    issue = {"valu_insts_per_launch": int(valu), "floor_insts": int(floor), "valu_floor_frac": round(floor / valu, 4),
+                             "achieved_ginst_s": round(rate, 1), "peak_ginst_s": VALU_PEAK_GINST_S,
+                             "frac": round(rate / VALU_PEAK_GINST_S, 4)}
+            else:
+                pmc_note = "profiles/traffic_latest.json was measured on other kernel sources: re-run tools/gpu_bench_profile.sh"
         out = {
             "metric": "Mrays/s (primary+shadow), 1920x1080 into depth-12 SVO",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -278,41 +337,102 @@ def main():
                                    f"{W}x{H}{'' if world == 1 else f' x{world} rows (vertical supersampling)'}, "
                                    "primary + 1-light shadow + Blinn-Phong + texture atlas, max_distance 3*dim",
                        "descriptors": int(sc["octree"].descriptor_buffer.size),
-                       "rays_per_step": int(total_rays), "parallelism": f"row-tiles x{world}, SVO replicated",
+                       "rays_per_step": int(total_rays), "parallelism": f"row-slices x{world}, SVO replicated",
                        "stepping": "exact per-voxel DDA (bit-identical to the reference array branch)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel": "raycast_svo_kernel",
-                         "note": "exact-parity stepping is VALU-issue bound (DESIGN.md 4): 8.4 G DDA steps vs 74 M descriptor reads per frame",
-                         "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"], "valu_issue": issue},
+                         "binding_roof": "valu_issue",
+                         "note": "exact-parity stepping is VALU-issue bound (DESIGN.md 4): frac is kept on HBM as BASELINE defines it, "
+                                 "valu_issue.frac says how close the kernel is to the roof that binds it",
+                         "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"], "valu_issue": issue,
+                         "pmc_source": pmc_note, "kernel_source_hash": kernel_source_hash()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            # supplementary: two frames in flight (a second caster = second HIP stream + its own buffers) hide the
-            # kernel's ramp-up and tail; the headline `value` above is one frame at a time, like CLCaster::compute
-            c2 = make_caster(sc, W, H, local_rank)
-            for _ in range(2):
-                assert c2.compute(), c2.last_error()
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            pairs = max(args.steps // 2, 1)
-            for _ in range(pairs):
-                assert c.compute_async() and c2.compute_async()
-                assert c.sync() and c2.sync()
-            dtp = time.perf_counter() - tp
-            out["two_frames_in_flight"] = {"value": round(rays_per_step * 2 * pairs / dtp / 1e6, 3), "unit": "Mrays/s",
-                                           "ms_per_frame": round(dtp / (2 * pairs) * 1e3, 4)}
-            del c2
-            rays, secs, used, cores, nrows, same = cpu_baseline(sc, W, H, gpu_frame=c.read_image())
-            out["cpu_baseline"] = {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": used, "kind": "port",
-                                   "sample": f"{nrows} of {H} rows of the same frame, oracle/vrc_oracle.c (scalar C, OpenMP over rows), "
-                                             f"{used} of {cores} host threads; {rays} rays in {secs:.2f} s",
-                                   "gpu_frame_bit_identical_on_sample": same,
-                                   "ray_cpp": ray_cpp_baseline()}
+            out.update(supplementary(sc, c, W, H, local_rank, args, rays_per_step))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def supplementary(sc, c, W, H, device, args, rays_per_step):
+    """N = 1 extras, never part of `value`: production frame without hit records, two frames in flight, the node-exit
+    jump mode (SURVEY D1 mode B) with its mismatch statistics, and the CPU baselines."""
+    import torch
+    out = {}
+    # production frame: the reference writes no hit records (they exist for parity tests)
+    assert c.overwrite_setting("hit_records", 0)
+    for _ in range(2):
+        assert c.compute(), c.last_error()
+    c.timing_reset()
+    for _ in range(args.steps):
+        assert c.compute(), c.last_error()
+    nl, ms = c.timing()
+    out["no_hit_records"] = {"kernel_ms_avg": round(ms / nl, 4), "value": round(rays_per_step / (ms / nl) / 1e3, 3), "unit": "Mrays/s (kernel time)"}
+    assert c.overwrite_setting("hit_records", 1) and c.compute()
+    # two frames in flight (a second caster = second HIP stream + its own buffers) hide the kernel's ramp-up and tail;
+    # the headline `value` is one frame at a time, like CLCaster::compute
+    c2 = make_caster(sc, W, H, device)
+    for _ in range(2):
+        assert c2.compute(), c2.last_error()
+    torch.cuda.synchronize()
+    tp = time.perf_counter()
+    pairs = max(args.steps // 2, 1)
+    for _ in range(pairs):
+        assert c.compute_async() and c2.compute_async()
+        assert c.sync() and c2.sync()
+    dtp = time.perf_counter() - tp
+    out["two_frames_in_flight"] = {"value": round(rays_per_step * 2 * pairs / dtp / 1e6, 3), "unit": "Mrays/s",
+                                   "ms_per_frame": round(dtp / (2 * pairs) * 1e3, 4)}
+    del c2
+    gpu_frame = c.read_image()
+    try:
+        out["mode_b_node_exit_jumps"] = mode_b_report(sc, c, W, H, args, gpu_frame)
+    except Exception as e:                     # the supplementary mode must never take the headline line down
+        out["mode_b_node_exit_jumps"] = {"error": str(e)}
+    rays, secs, used, cores, nrows, same = cpu_baseline(sc, W, H, gpu_frame=gpu_frame)
+    out["cpu_baseline"] = {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": used, "kind": "port",
+                           "sample": f"{nrows} of {H} rows of the same frame, oracle/vrc_oracle.c (scalar C, OpenMP over pixels), "
+                                     f"{used} of {cores} host threads; {rays} rays in {secs:.2f} s",
+                           "gpu_frame_bit_identical_on_sample": same,
+                           "ray_cpp": ray_cpp_baseline()}
+    return out
+
+
+def mode_b_report(sc, c, W, H, args, exact_frame):
+    """SURVEY D1 mode B on the same frame: labelled, supplementary, never `value`.  Its own roofline (same algorithmic
+    byte formula, its own counters and kernel time) and how far it is from the exact mode."""
+    exact_hits = c.read_hits()
+    if not c.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", 1):
+        raise RuntimeError(c.last_error())
+    try:
+        for _ in range(2):
+            if not c.compute():
+                raise RuntimeError(c.last_error())
+        ctr = c.counters()
+        c.timing_reset()
+        for _ in range(args.steps):
+            assert c.compute(), c.last_error()
+        nl, ms = c.timing()
+        img, hits = c.read_image(), c.read_hits()
+    finally:
+        c.overwrite_setting("stepping_mode", 0)
+    pixels = W * H
+    b = algorithmic_bytes(ctr, pixels, pixels - ctr["unwritten_pixels"])
+    k = ms / nl / 1e3
+    same_voxel = (hits[..., :5] == exact_hits[..., :5]).all(-1)
+    rel = np.abs(img[..., :3] - exact_frame[..., :3]) / np.maximum(np.abs(exact_frame[..., :3]), 1e-6)
+    return {"kernel_ms_avg": round(k * 1e3, 4), "value": round((ctr["primary_rays"] + ctr["shadow_rays"]) / k / 1e6, 3),
+            "unit": "Mrays/s (kernel time)",
+            "roofline": {"bound": "hbm", "achieved": round(b / k / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(b / k / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": int(b),
+                         "descriptor_reads": ctr["descriptor_reads"], "node_steps": ctr["steps"]},
+            "vs_exact_mode": {"pixels_same_hit_voxel_face_material": round(float(same_voxel.mean()), 6),
+                              "pixels_rgb_within_1e-5": round(float((rel.max(-1) <= 1e-5).mean()), 6)},
+            "parity": "bit-exact against its own restatement in oracle/ (tests/test_mode_b_gpu.py); a different float "
+                      "sequence from the reference array branch by construction"}
 
 
 if __name__ == "__main__":

@@ -127,7 +127,11 @@ int vrc_assign_lights(vrc_caster *h, const float *packed, const int32_t *light_c
  *   octree_root_index  (OCTREE_ROOT_INDEX) set by vrc_assign_octree
  * extensions (defaults reproduce the reference):
  *   max_distance (20)  shadow_rays (1)  light_count (1, see vrc_assign_lights)
- *   octree_bias (1: the :353-354 term as in the reference; 0: without it)    */
+ *   octree_bias (1: the :353-354 term as in the reference; 0: without it)
+ *   hit_records (1: the 8 x int32 record per pixel behind vrc_read_hits; 0: none -- the reference has none)
+ *   stepping_mode (0: exact per-voxel DDA, bit-identical to the array branch; 1: node-exit jumps, DESIGN.md "mode B")
+ * Settings stay live after vrc_validate (overwrite_setting needs no recompile); structural ones are re-checked by
+ * every vrc_compute, which fails with an error code instead of launching on a bad value.                            */
 int vrc_setting_add(vrc_caster *h, const char *name, const char *define, int64_t value);
 /* CLCaster::overwrite_setting (CLCaster.cpp:1087-1109) */
 int vrc_setting_set(vrc_caster *h, const char *name, int64_t value);
@@ -149,14 +153,43 @@ int vrc_sync(vrc_caster *h);
 
 /* Multi-GPU row tiling: this handle renders only the bands
  * b with b % world == rank, a band being `band_rows` consecutive image rows
- * (multiple of 8).  Default rank 0 / world 1 = the whole image.              */
+ * (multiple of 8).  Default rank 0 / world 1 = the whole image.  The buffers
+ * stay full-frame (rows of other ranks keep their previous contents).        */
 int vrc_set_row_tiling(vrc_caster *h, int32_t rank, int32_t world, int32_t band_rows);
+/* Same partition, but the ray table, the frame and the hit records hold ONLY this rank's rows (SURVEY 8e "sliced per
+ * GPU: ray table rows and framebuffer rows"): per-rank memory and uploads are 1/world of the frame.  Call before
+ * vrc_create_viewport(_table); the read-back calls then fill this rank's rows of the caller's full frame and leave the
+ * others alone, so world handles reading into one buffer assemble the frame.                                        */
+int vrc_set_row_slice(vrc_caster *h, int32_t rank, int32_t world, int32_t band_rows);
+
+/* One host thread, n GPUs (SURVEY 8b "Compute", 8e): the returned handle is rank 0 of a group of n handles
+ * (device_ordinals[r] for rank r; the same ordinal may repeat), row-sliced in bands of band_rows.  Every call on the
+ * group handle is replicated on all ranks: the octree is uploaded (or built) once on rank 0's GPU and fanned out
+ * device to device (hipMemcpyPeerAsync; ranks on rank 0's own GPU share its arrays), vrc_compute launches every rank
+ * and returns when the frame is complete on all of them -- the one synchronous compute() of CLCaster.cpp:224-228,946-987
+ * -- vrc_read_* gather every rank's rows into the caller's frame (each GPU copies its own tile, no collective),
+ * vrc_get_counters sums the ranks.  vrc_destroy on the group handle destroys all ranks.                            */
+int vrc_create_group(const int32_t *device_ordinals, int32_t n, int32_t band_rows, vrc_caster **out);
+int vrc_group_size(const vrc_caster *h, int32_t *n);
+/* Pin / unpin a caller-owned frame buffer so the per-rank tile copies overlap (hipHostRegister). */
+int vrc_pin_host_buffer(void *p, size_t bytes);
+int vrc_unpin_host_buffer(void *p);
+/* Device memory held by one rank of a group (rank 0 = the handle itself). */
+typedef struct vrc_memory {
+    int32_t  device, rows;            /* GPU ordinal; rows of the frame this rank's buffers hold */
+    uint64_t viewport_bytes, image_bytes, hit_bytes, octree_bytes;
+    int32_t  octree_shared;           /* 1: the arrays belong to rank 0 (same GPU) */
+} vrc_memory;
+int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out);
 
 /* ---- output ------------------------------------------------------------ */
 
 /* CLCaster::draw (CLCaster.cpp:330-332) has no read-back; these replace it.
  * n_floats / n_bytes / n_int32 are the capacities of the caller's buffers.   */
 int vrc_read_image_f32(vrc_caster *h, float *rgba, size_t n_floats);
+/* What CLCaster::draw shows: the reference's output IS an RGBA8 texture (CLCaster.cpp:278-296,330-332).  The frame is
+ * quantised on the device (saturate, x255, round to nearest even, like write_imagef to CL_UNORM_INT8) and 4 bytes per
+ * pixel are read back.                                                                                              */
 int vrc_read_image_rgba8(vrc_caster *h, uint8_t *rgba, size_t n_bytes);
 /* 8 int32 per pixel: voxel x,y,z of the primary hit (-1 if none), material,
  * face bits, flags, final step count, canonical descriptor reads.            */
@@ -237,6 +270,41 @@ int vrc_scene_shell_terrain_dense(uint32_t depth, uint64_t seed, int32_t thickne
  * grid (optional, int8[dim^3], x + dim*(y + dim*z)): what ApplyHeightmap was meant to do -- material 5 at and
  * below the height of each column, 0 above (our definition; the reference has none).                            */
 int vrc_scene_diamond_square(uint32_t dim, double corner_seed, uint8_t *height, int8_t *grid);
+
+/* The same scene with its knobs exposed: octave_floor = log2 of the finest noise cell (2 in vrc_scene_shell_terrain),
+ * layout = VRC_LAYOUT_* flags.  VRC_LAYOUT_NO_PAGE_HEADERS is the "brick" layout the device builder emits: same
+ * descriptor format and bottom-up order, no all-ones page-header slots (they are the only position-dependent part of
+ * the reference layout, Octree.cpp:251-262, and neither kernel reads them).                                          */
+#define VRC_LAYOUT_STRICT_REFERENCE 1u
+#define VRC_LAYOUT_NO_PAGE_HEADERS  2u
+int vrc_scene_shell_terrain_ex(uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor, uint32_t layout,
+                               uint64_t **descriptors, uint64_t *n_descriptors, uint64_t *root_index, int32_t *height);
+/* One column of that scene, evaluated procedurally: solid for lo <= z <= hi. */
+int vrc_scene_shell_column(uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor, int64_t x, int64_t y,
+                           int32_t *lo, int32_t *hi);
+
+/* Builds the scene's SVO directly in the handle's HBM and installs it as the octree (no host copy ever exists):
+ * replaces the reference builder's limits -- Octree::buffer_size = 100000 descriptors (include/map/Octree.h:29) and the
+ * dense char[D^3] input of Octree::Generate (src/map/Octree.cpp:13,325-327).  The array is bit-identical to
+ * vrc_scene_shell_terrain_ex(..., VRC_LAYOUT_NO_PAGE_HEADERS).  flags: VRC_BUILD_COUNT_ONLY sizes the tree without
+ * allocating it.  validate_samples > 0 runs the reference's Octree::Validate (Octree.cpp:329-352) on the device over
+ * that many pseudo-random voxels (tree point query vs the procedural occupancy).  probe_xy (n_probe x,y pairs) /
+ * probe_lohi (n_probe lo,hi pairs): optional read-back of columns of the device height field.                      */
+#define VRC_BUILD_COUNT_ONLY 1u
+typedef struct vrc_build_info {
+    uint64_t n_descriptors, root_index;
+    uint64_t n_bricks, n_top_slots, n_far_pointers_top;
+    double   seconds_total, seconds_height, seconds_count, seconds_emit;
+    uint64_t device_bytes_peak;      /* descriptor array + builder temporaries */
+    uint64_t host_bytes;             /* brick tables held on the host while building */
+    uint64_t validate_samples, validate_mismatches;
+} vrc_build_info;
+int vrc_build_shell_terrain(vrc_caster *h, uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor,
+                            uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
+                            int32_t *probe_lohi, vrc_build_info *info);
+/* Read descriptors [first, first + count) of the resident octree back to the host (tests, tools). */
+int vrc_read_descriptors(vrc_caster *h, uint64_t first, uint64_t count, uint64_t *out);
+int vrc_octree_size(vrc_caster *h, uint64_t *n_descriptors, uint64_t *root_index);
 
 /* Synthetic 256x256-style atlas: texel = hash(x,y) & 0xFFFFFF, alpha 255.    */
 int vrc_scene_atlas(int32_t width, int32_t height, uint8_t *rgba8);

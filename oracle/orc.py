@@ -52,7 +52,39 @@ class Scene(C.Structure):
         ("attachment_lookup", C.POINTER(C.c_uint32)), ("attachments", _u64p),
         ("octree_dimensions", C.c_int64), ("using_octree", C.c_int64), ("octree_root_index", C.c_int64),
         ("max_distance", C.c_int32), ("shadow_rays", C.c_int32), ("no_bias", C.c_int32), ("active_lights", C.c_int32),
-        ("cam_trig", C.c_float * 4)]
+        ("cam_trig", C.c_float * 4),
+        ("desc_pages", C.POINTER(C.c_void_p)), ("desc_page_fetch", C.c_void_p), ("desc_page_user", C.c_void_p)]
+
+
+PAGE_SHIFT = 12
+PAGE_SIZE = 1 << PAGE_SHIFT
+PAGE_FETCH = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)
+
+
+class PagedDescriptors:
+    """Descriptor source for trees that exist only in GPU memory: read(first, count) -> uint64 array is called once per
+    page of PAGE_SIZE descriptors the oracle touches; pages are kept for the lifetime of this object."""
+
+    def __init__(self, n_descriptors: int, read):
+        self.n = int(n_descriptors)
+        self.read = read
+        self.n_pages = (self.n + PAGE_SIZE - 1) >> PAGE_SHIFT
+        self.table = np.zeros(self.n_pages, dtype=np.uint64)       # the oracle's page table (pointers)
+        self.pages = {}
+
+        def fetch(_user, page):
+            first = int(page) << PAGE_SHIFT
+            buf = np.zeros(PAGE_SIZE, dtype=np.uint64)
+            cnt = min(PAGE_SIZE, self.n - first)
+            buf[:cnt] = self.read(first, cnt)
+            self.pages[int(page)] = buf
+            return buf.ctypes.data
+
+        self.callback = PAGE_FETCH(fetch)
+
+    @property
+    def bytes_fetched(self) -> int:
+        return len(self.pages) * PAGE_SIZE * 8
 
 
 class Counters(C.Structure):
@@ -164,10 +196,15 @@ def raycast(*, width, height, cam_dir, cam_pos, lights, atlas, tile_dim, descrip
     s.atlas_rgba8 = _p(at, _u8p)
     s.atlas_dim = (C.c_int32 * 2)(at.shape[1], at.shape[0])
     s.tile_dim = (C.c_int32 * 2)(*tile_dim)
-    de = np.ascontiguousarray(descriptors, dtype=np.uint64)
-    keep.append(de)
-    s.descriptors = _p(de, _u64p)
-    s.n_descriptors = de.size
+    if isinstance(descriptors, PagedDescriptors):
+        s.n_descriptors = descriptors.n
+        s.desc_pages = descriptors.table.ctypes.data_as(C.POINTER(C.c_void_p))
+        s.desc_page_fetch = C.cast(descriptors.callback, C.c_void_p)
+    else:
+        de = np.ascontiguousarray(descriptors, dtype=np.uint64)
+        keep.append(de)
+        s.descriptors = _p(de, _u64p)
+        s.n_descriptors = de.size
     if attachment_lookup is not None and attachments is not None:
         al = np.ascontiguousarray(attachment_lookup, dtype=np.uint32)
         ab = np.ascontiguousarray(attachments, dtype=np.uint64)

@@ -87,4 +87,73 @@ int ref_probe_get_oct_vox(const char *code_object, const int32_t *positions, int
     return 0;
 }
 
+// The reference's own `raycaster` kernel (oracle/ref_raycaster_probe.cl: image builtins redirected to buffers).
+// Buffers as CLCaster binds them (CLCaster.cpp:186-202); records: 32 ints per pixel (layout in the .cl file), zeroed
+// first; trig_out: sin/cos of the camera angles as this code object evaluates them.  width and height must be
+// multiples of 8 (the kernel has no bounds check: the reference launches exactly W x H work-items).
+int ref_probe_raycaster(const char *code_object, const int8_t *map, const int32_t map_dim[3], int32_t width, int32_t height,
+                        const float *viewport_matrix, const float cam_dir[2], const float cam_pos[3], const float *lights10,
+                        int32_t n_lights, const uint32_t *atlas_rgba8, const int32_t atlas_dim[2], const int32_t tile_dim[2],
+                        const uint64_t *descriptors, uint64_t n_descriptors, uint64_t root_index, int64_t octree_dim,
+                        int64_t oct_enabled, int32_t *records, float *trig_out) {
+    if (width % 8 || height % 8) { g_error = "width and height must be multiples of 8"; return 1; }
+    Module m;
+    if (m.load(code_object)) return 1;
+    hipFunction_t f, ftrig;
+    TRY(hipModuleGetFunction(&f, m.mod, "raycaster"));
+    TRY(hipModuleGetFunction(&ftrig, m.mod, "probe_trig"));
+    const size_t npix = (size_t)width * height, nmap = (size_t)map_dim[0] * map_dim[1] * map_dim[2];
+    const size_t natlas = (size_t)atlas_dim[0] * atlas_dim[1];
+    DevBuf<int8_t> dmap;
+    DevBuf<int32_t> dmapdim, dres, dlc, datlasdim, dtiledim, drec;
+    DevBuf<float> dvm, dcamdir, dcampos, dlights, dtrig;
+    DevBuf<uint32_t> datlas;
+    DevBuf<uint64_t> ddesc, dsettings, ddummy;
+    uint64_t settings[64];
+    memset(settings, 0, sizeof(settings));
+    settings[0] = (uint64_t)octree_dim; settings[1] = (uint64_t)oct_enabled; settings[2] = root_index;
+    const int32_t mapdim4[4] = {map_dim[0], map_dim[1], map_dim[2], 0}, res2[2] = {width, height};
+    const float camdir4[4] = {cam_dir[0], cam_dir[1], 0, 0}, campos4[4] = {cam_pos[0], cam_pos[1], cam_pos[2], 0};
+    TRY(hipMalloc((void **)&dmap.p, nmap));
+    TRY(hipMalloc((void **)&dmapdim.p, 16)); TRY(hipMalloc((void **)&dres.p, 8)); TRY(hipMalloc((void **)&dlc.p, 8));
+    TRY(hipMalloc((void **)&datlasdim.p, 8)); TRY(hipMalloc((void **)&dtiledim.p, 8));
+    TRY(hipMalloc((void **)&drec.p, npix * 32 * sizeof(int32_t)));
+    TRY(hipMalloc((void **)&dvm.p, npix * 16)); TRY(hipMalloc((void **)&dcamdir.p, 16)); TRY(hipMalloc((void **)&dcampos.p, 16));
+    TRY(hipMalloc((void **)&dlights.p, sizeof(float) * 10 * 8)); TRY(hipMalloc((void **)&dtrig.p, 16));
+    TRY(hipMalloc((void **)&datlas.p, natlas * 4));
+    TRY(hipMalloc((void **)&ddesc.p, n_descriptors * 8)); TRY(hipMalloc((void **)&dsettings.p, sizeof(settings)));
+    TRY(hipMalloc((void **)&ddummy.p, 64));
+    TRY(hipMemcpy(dmap.p, map, nmap, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dmapdim.p, mapdim4, 16, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dres.p, res2, 8, hipMemcpyHostToDevice));
+    int32_t lc2[2] = {n_lights, 0};
+    TRY(hipMemcpy(dlc.p, lc2, 8, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(datlasdim.p, atlas_dim, 8, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dtiledim.p, tile_dim, 8, hipMemcpyHostToDevice));
+    TRY(hipMemset(drec.p, 0, npix * 32 * sizeof(int32_t)));
+    TRY(hipMemcpy(dvm.p, viewport_matrix, npix * 16, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dcamdir.p, camdir4, 16, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dcampos.p, campos4, 16, hipMemcpyHostToDevice));
+    TRY(hipMemset(dlights.p, 0, sizeof(float) * 80));
+    TRY(hipMemcpy(dlights.p, lights10, sizeof(float) * 10 * (size_t)(n_lights < 8 ? n_lights : 8), hipMemcpyHostToDevice));
+    TRY(hipMemcpy(datlas.p, atlas_rgba8, natlas * 4, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(ddesc.p, descriptors, n_descriptors * 8, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dsettings.p, settings, sizeof(settings), hipMemcpyHostToDevice));
+    TRY(hipMemset(ddummy.p, 0, 64));
+    {
+        void *args[] = {&dcamdir.p, &dtrig.p};
+        TRY(hipModuleLaunchKernel(ftrig, 1, 1, 1, 1, 1, 1, 0, nullptr, args, nullptr));
+    }
+    // the 16 kernel arguments in the reference's order; the two image2d_t arguments are dead after the redirection
+    // and get a null descriptor pointer
+    void *null_image = nullptr;
+    void *args[] = {&dmap.p, &dmapdim.p, &dres.p, &dvm.p, &dcamdir.p, &dcampos.p, &dlights.p, &dlc.p, &null_image, &null_image,
+                    &datlasdim.p, &dtiledim.p, &ddesc.p, &datlas.p, &drec.p, &dsettings.p};
+    TRY(hipModuleLaunchKernel(f, (unsigned)(width / 8), (unsigned)(height / 8), 1, 8, 8, 1, 0, nullptr, args, nullptr));
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(records, drec.p, npix * 32 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(trig_out, dtrig.p, 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 }  // extern "C"

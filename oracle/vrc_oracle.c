@@ -143,13 +143,49 @@ int orc_octree_generate(const int8_t *grid, int dim, uint64_t *buffer, uint64_t 
 }
 
 /* ======================================================================= */
+/* Where descriptors come from: the flat array (kernel arg 12), or -- for trees that only exist in the GPU's memory
+ * (the ~200 GB scene of BASELINE configs[4]) -- pages of ORC_PAGE_SIZE descriptors fetched on demand through a
+ * callback and kept in a page table.  Either way the same indices are read.                                     */
+typedef struct {
+    const uint64_t   *flat;
+    const uint64_t  **pages;
+    orc_page_fetch_fn fetch;
+    void             *user;
+} desc_src;
+
+static const uint64_t *fetch_page(const desc_src *src, uint64_t page) {
+    const uint64_t *p;
+#pragma omp critical(orc_desc_page)
+    {
+        p = __atomic_load_n(&src->pages[page], __ATOMIC_ACQUIRE);
+        if (!p) {
+            p = src->fetch(src->user, page);
+            __atomic_store_n((const uint64_t **)&src->pages[page], p, __ATOMIC_RELEASE);
+        }
+    }
+    return p;
+}
+
+static inline uint64_t desc_at(const desc_src *src, uint64_t i) {
+    if (!src->fetch) return src->flat[i];
+    const uint64_t *p = __atomic_load_n(&src->pages[i >> ORC_PAGE_SHIFT], __ATOMIC_ACQUIRE);
+    if (!p) p = fetch_page(src, i >> ORC_PAGE_SHIFT);
+    return p[i & (ORC_PAGE_SIZE - 1)];
+}
+
+static desc_src scene_src(const orc_scene *s) {
+    desc_src src = {s->descriptors, s->desc_pages, s->desc_page_fetch, s->desc_page_user};
+    return src;
+}
+
+/* ======================================================================= */
 /* a3: get_oct_vox  (kernels/ray_caster_kernel.cl:140-251)                  */
 
-void orc_get_oct_vox(const int32_t position[3], const uint64_t *descriptors,
-                     uint64_t root_index, int32_t dim, orc_traversal_state *ts) {
+static void get_oct_vox_src(const int32_t position[3], const desc_src *descriptors,
+                            uint64_t root_index, int32_t dim, orc_traversal_state *ts) {
     memset(ts, 0, sizeof(*ts));
     ts->current_descriptor_index = root_index;                    /* :150-151 */
-    ts->current_descriptor = descriptors[root_index];
+    ts->current_descriptor = desc_at(descriptors, root_index);
     ts->reads = 1;
     ts->scale = 0;
     ts->parent_stack_position = 0;
@@ -185,14 +221,14 @@ void orc_get_oct_vox(const int32_t position[3], const uint64_t *descriptors,
 
             int count = __builtin_popcount((uint8_t)(ts->current_descriptor >> 16) & count_mask_8[mask_index]) - 1;
 
-            if (ORC_FAR_BIT_MASK & descriptors[ts->current_descriptor_index]) {   /* :222-225 */
+            if (ORC_FAR_BIT_MASK & desc_at(descriptors, ts->current_descriptor_index)) {   /* :222-225 */
                 uint64_t far_pointer_index = ts->current_descriptor_index + (ts->current_descriptor & ORC_CHILD_POINTER_MASK);
-                ts->current_descriptor_index = descriptors[far_pointer_index] + (uint64_t)(int64_t)count;
+                ts->current_descriptor_index = desc_at(descriptors, far_pointer_index) + (uint64_t)(int64_t)count;
             } else {                                              /* :228-230 */
                 ts->current_descriptor_index = ts->current_descriptor_index
                     + (ts->current_descriptor & ORC_CHILD_POINTER_MASK) + (uint64_t)(int64_t)count;
             }
-            ts->current_descriptor = descriptors[ts->current_descriptor_index];   /* :233 */
+            ts->current_descriptor = desc_at(descriptors, ts->current_descriptor_index);   /* :233 */
             ts->reads++;
             ts->parent_stack[ts->parent_stack_position] = ts->current_descriptor;
             ts->parent_stack_index[ts->parent_stack_position] = ts->current_descriptor_index;
@@ -202,6 +238,12 @@ void orc_get_oct_vox(const int32_t position[3], const uint64_t *descriptors,
         }
     }
     ts->found = 1;                                                /* :249 */
+}
+
+void orc_get_oct_vox(const int32_t position[3], const uint64_t *descriptors,
+                     uint64_t root_index, int32_t dim, orc_traversal_state *ts) {
+    const desc_src src = {descriptors, NULL, NULL, NULL};
+    get_oct_vox_src(position, &src, root_index, dim, ts);
 }
 
 int64_t orc_octree_validate(const int8_t *grid, int dim, const uint64_t *descriptors,
@@ -320,7 +362,7 @@ static void atlas_fetch(const orc_scene *s, int tx, int ty, float out[4]) {
  * One descriptor read for the root per ray, one per descent into a kept
  * child; pops and steps inside a known-empty node cost nothing.            */
 typedef struct {
-    const uint64_t *descriptors;
+    desc_src descriptors;
     int      n;                       /* log2(dim) */
     int      top;
     uint64_t desc[ORC_MAX_DEPTH];
@@ -329,13 +371,13 @@ typedef struct {
     uint32_t reads;
 } svo_cursor;
 
-static void svo_init(svo_cursor *c, const uint64_t *descriptors, uint64_t root_index, int dim) {
-    c->descriptors = descriptors;
+static void svo_init(svo_cursor *c, const desc_src *descriptors, uint64_t root_index, int dim) {
+    c->descriptors = *descriptors;
     c->n = 0;
     while ((1 << c->n) < dim) c->n++;
     c->top = 0;
     c->idx[0] = root_index;
-    c->desc[0] = descriptors[root_index];
+    c->desc[0] = desc_at(descriptors, root_index);
     c->pv[0] = c->pv[1] = c->pv[2] = 0;
     c->reads = 1;
 }
@@ -356,12 +398,12 @@ static int svo_locate(svo_cursor *c, const int32_t v[3]) {
         uint64_t at = c->idx[c->top];
         uint64_t child;
         if (d & ORC_FAR_BIT_MASK)
-            child = c->descriptors[at + (d & ORC_CHILD_POINTER_MASK)] + (uint64_t)(int64_t)count;
+            child = desc_at(&c->descriptors, at + (d & ORC_CHILD_POINTER_MASK)) + (uint64_t)(int64_t)count;
         else
             child = at + (d & ORC_CHILD_POINTER_MASK) + (uint64_t)(int64_t)count;
         c->top++;
         c->idx[c->top] = child;
-        c->desc[c->top] = c->descriptors[child];
+        c->desc[c->top] = desc_at(&c->descriptors, child);
         c->reads++;
     }
 }
@@ -480,7 +522,8 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
     svo_cursor cur;
     uint32_t ndesc = 0;
     if (svo) {
-        svo_init(&cur, s->descriptors, (uint64_t)s->octree_root_index, (int)s->octree_dimensions);
+        const desc_src src = scene_src(s);
+        svo_init(&cur, &src, (uint64_t)s->octree_root_index, (int)s->octree_dimensions);
         /* the per-pixel get_oct_vox(camera voxel) of the reference == the
          * cursor's first descent (only meaningful when the camera is inside
          * the map; otherwise only the root read is charged)                  */
@@ -696,8 +739,8 @@ void orc_raycast(const orc_scene *s, int32_t y0, int32_t y1, float *image, int32
     int32_t cam_voxel[3], bias[3];
     for (int a = 0; a < 3; a++) cam_voxel[a] = (int32_t)floorf(s->cam_pos[a]);
     orc_traversal_state ts;
-    orc_get_oct_vox(cam_voxel, s->descriptors, (uint64_t)s->octree_root_index,
-                    (int32_t)s->octree_dimensions, &ts);
+    const desc_src src = scene_src(s);
+    get_oct_vox_src(cam_voxel, &src, (uint64_t)s->octree_root_index, (int32_t)s->octree_dimensions, &ts);
     for (int a = 0; a < 3; a++)
         bias[a] = s->no_bias ? 0 : (ts.sub_oct_pos[a] - cam_voxel[a]) * ts.resolution / 2;
 
@@ -707,22 +750,24 @@ void orc_raycast(const orc_scene *s, int32_t y0, int32_t y1, float *image, int32
     const int array_mode_reads = ts.reads;   /* array branch: get_oct_vox reads per pixel */
     const int svo = (s->using_octree == 0);
 
+    /* pixels are independent: chunks of 32 go to the threads dynamically, so even a single row keeps every thread busy */
+    const int64_t p0 = (int64_t)y0 * W, p1 = (int64_t)y1 * W;
 #ifdef _OPENMP
     if (threads > 1) {
 #pragma omp parallel num_threads(threads)
         {
             orc_counters local;
             memset(&local, 0, sizeof(local));
-#pragma omp for schedule(dynamic, 1)
-            for (int y = y0; y < y1; y++)
-                for (int x = 0; x < W; x++) {
-                    uint64_t before = local.primary_rays;
-                    raycast_pixel(s, x, y, bias, image, hits, &local);
-                    if (!svo && local.primary_rays != before) {
-                        local.n_desc += (uint64_t)array_mode_reads;
-                        if (hits) hits[8 * ((int64_t)x + (int64_t)W * y) + ORC_HIT_NDESC] = array_mode_reads;
-                    }
+#pragma omp for schedule(dynamic, 32)
+            for (int64_t q = p0; q < p1; q++) {
+                const int x = (int)(q % W), y = (int)(q / W);
+                uint64_t before = local.primary_rays;
+                raycast_pixel(s, x, y, bias, image, hits, &local);
+                if (!svo && local.primary_rays != before) {
+                    local.n_desc += (uint64_t)array_mode_reads;
+                    if (hits) hits[8 * q + ORC_HIT_NDESC] = array_mode_reads;
                 }
+            }
 #pragma omp critical
             add_counters(&total, &local);
         }
@@ -730,15 +775,15 @@ void orc_raycast(const orc_scene *s, int32_t y0, int32_t y1, float *image, int32
 #endif
     {
         (void)threads;
-        for (int y = y0; y < y1; y++)
-            for (int x = 0; x < W; x++) {
-                uint64_t before = total.primary_rays;
-                raycast_pixel(s, x, y, bias, image, hits, &total);
-                if (!svo && total.primary_rays != before) {
-                    total.n_desc += (uint64_t)array_mode_reads;
-                    if (hits) hits[8 * ((int64_t)x + (int64_t)W * y) + ORC_HIT_NDESC] = array_mode_reads;
-                }
+        for (int64_t q = p0; q < p1; q++) {
+            const int x = (int)(q % W), y = (int)(q / W);
+            uint64_t before = total.primary_rays;
+            raycast_pixel(s, x, y, bias, image, hits, &total);
+            if (!svo && total.primary_rays != before) {
+                total.n_desc += (uint64_t)array_mode_reads;
+                if (hits) hits[8 * q + ORC_HIT_NDESC] = array_mode_reads;
             }
+        }
     }
     if (counters) add_counters(counters, &total);
 }

@@ -89,6 +89,13 @@ int64_t orc_octree_validate(const int8_t *grid, int dim, const uint64_t *descrip
  * float4[w*h], zero-initialised here; w component = 0.                       */
 void orc_create_viewport(int32_t w, int32_t h, float *table);
 
+/* Descriptors of a tree that lives only in GPU memory reach the oracle in pages: the callback returns a pointer to
+ * descriptors [page * ORC_PAGE_SIZE, (page + 1) * ORC_PAGE_SIZE) that stays valid for the whole orc_raycast call
+ * (the tail of the last page may be padding).  Called under a lock, from any OpenMP thread.                     */
+#define ORC_PAGE_SHIFT 12
+#define ORC_PAGE_SIZE  (1u << ORC_PAGE_SHIFT)
+typedef const uint64_t *(*orc_page_fetch_fn)(void *user, uint64_t page);
+
 /* ---- a5/a6: the kernel */
 typedef struct {
     /* kernel args 0..15 (CLCaster.cpp:186-202) */
@@ -118,6 +125,11 @@ typedef struct {
     int32_t         active_lights;       /* <= 1: light 0 only (the reference); n: the first n lights, each
                                             from the first strike (see light_from_strike)       */
     float           cam_trig[4];         /* sin(dir.x) cos(dir.x) sin(dir.y) cos(dir.y) */
+    /* optional paged descriptor source (see ORC_PAGE_SIZE): when desc_page_fetch is set, `descriptors` is not read;
+     * desc_pages is a zero-initialised table of ceil(n_descriptors / ORC_PAGE_SIZE) pointers the oracle fills */
+    const uint64_t  **desc_pages;
+    orc_page_fetch_fn desc_page_fetch;
+    void             *desc_page_user;
 } orc_scene;
 
 typedef struct {

@@ -326,8 +326,9 @@ def test_async_frames_timing_and_settings_queries(atlas):
 
 
 def test_round_watchdog_reports_instead_of_hanging(atlas):
-    """A wave that would run more rounds than any legal frame needs is stopped and vrc_get_counters reports it
-    (setting watchdog_rounds only exists to provoke this); a normal frame never trips it."""
+    """A wave that would run more rounds than any legal frame needs is stopped; compute() itself then fails (a truncated
+    frame never looks like success) and so does vrc_get_counters (setting watchdog_rounds only exists to provoke this);
+    a normal frame never trips it."""
     s = scenes.floor_pillars()
     dim, w, h, md = s["dim"], 128, 96, 3 * s["dim"]
     o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
@@ -335,7 +336,8 @@ def test_round_watchdog_reports_instead_of_hanging(atlas):
     assert c.compute()
     good = c.counters()
     assert good["primary_rays"] == w * h
-    assert c.add_to_settings_buffer("watchdog_rounds", "WATCHDOG_ROUNDS", 2) and c.compute()
+    assert c.add_to_settings_buffer("watchdog_rounds", "WATCHDOG_ROUNDS", 2)
+    assert c.compute() is False and c.last_status == 3 and "watchdog" in c.last_error()
     with pytest.raises(vrc.VrcError):
         c.counters()
     assert "watchdog" in c.last_error()
@@ -506,6 +508,10 @@ def test_cpp_host_mirror(tmp_path, atlas):
     assert np.array_equal(hits, ohits)
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=3)
 def _bench_scene(depth):
     import bench
     return bench.build_scene(depth)
@@ -631,26 +637,6 @@ def test_depth14_scene_sampled_rows():
     img, hits, ctr = c.read_image(), c.read_hits(), c.counters()
     assert ctr["descriptor_reads"] == int(hits[..., 7].sum()) and ctr["primary_rays"] == w * h
     for y0 in (61, 533, 1002):
-        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=c._li,
-                                     atlas=sc["atlas"], tile_dim=(16, 16), descriptors=d, root_index=sc["octree"].root_index,
-                                     octree_dim=dim, using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=8)
-        assert np.array_equal(hits[y0], ohits[y0])
-        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
-
-
-@pytest.mark.skipif(os.environ.get("VRC_DEEP_TESTS") != "1", reason="builds a 45 GB SVO (3.5 min, 165 GB host RSS): set VRC_DEEP_TESTS=1")
-def test_depth16_scene_sampled_rows():
-    """BASELINE configs[4] depth: 65536^3, 5.69 G descriptors = 45.5 GB resident in HBM, 15 stack levels in LDS, far
-    pointers beyond 2^32 -- sampled rows of a 1920x1080 frame bit-exact vs the oracle."""
-    sc = _bench_scene(16)
-    w, h, dim = 1920, 1080, sc["dim"]
-    d = sc["octree"].descriptor_buffer
-    assert d.size > (1 << 32)
-    c = make_caster(sc["octree"], dim, 0, sc["cam_dir"], sc["cam_pos"], sc["lights"], sc["atlas"], w, h, 3 * dim)
-    assert c.compute(), c.last_error()
-    img, hits, ctr = c.read_image(), c.read_hits(), c.counters()
-    assert ctr["descriptor_reads"] == int(hits[..., 7].sum()) and ctr["primary_rays"] == w * h
-    for y0 in (97, 540, 983):
         oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=c._li,
                                      atlas=sc["atlas"], tile_dim=(16, 16), descriptors=d, root_index=sc["octree"].root_index,
                                      octree_dim=dim, using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=8)

@@ -110,3 +110,113 @@ def test_get_oct_vox_of_the_oracle_matches_the_reference_function(probe, dim, de
         # and the grid agrees (Octree::Validate, src/map/Octree.cpp:329-352)
         assert bool(ts.found) == bool(grid[p[0] + dim * (p[1] + dim * p[2])])
     assert found_any
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's whole `raycaster` kernel on the MI355X, its two image builtins redirected to buffers
+# (oracle/ref_raycaster_probe.cl).  Two I/O builtins are overridden, so this CORROBORATES the oracle's ray set-up,
+# step loop (:555-570), hit block (:575-711) and epilogue (:716-721) rather than pinning them in the strict sense --
+# but a misreading of an OpenCL-C quirk shared by the oracle and the HIP kernels (vector compare = -1, comma
+# "literals", select's MSB rule, the :698 precedence) would show up here as a different hit voxel or step count.
+import scenes  # noqa: E402
+
+REC_WORDS = 32
+_RAYCASTER_ARGS = [C.c_char_p, C.POINTER(C.c_int8), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_float),
+                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_uint32),
+                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int64, C.c_int64,
+                   C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+
+
+def run_reference_raycaster(probe, code_object, s, w, h, atlas):
+    """-> (records int32[h, w, 32], trig float32[4], descriptor buffer, root index) of the reference kernel's frame."""
+    dim = s["dim"]
+    grid = np.ascontiguousarray(s["grid"], dtype=np.int8)
+    buf, root = orc.octree_generate(grid, dim)                      # Octree::Generate, 100000-entry buffer (Octree.h:29)
+    table = orc.create_viewport(w, h)                               # CLCaster::create_viewport
+    rec = np.zeros((h, w, REC_WORDS), dtype=np.int32)
+    trig = np.zeros(4, dtype=np.float32)
+    li = np.ascontiguousarray(s["lights"], dtype=np.float32).reshape(-1, 10)
+    at = np.ascontiguousarray(atlas, dtype=np.uint8).view(np.uint32).reshape(atlas.shape[0], atlas.shape[1])
+    probe.ref_probe_raycaster.argtypes = _RAYCASTER_ARGS
+    probe.ref_probe_raycaster.restype = C.c_int
+    rc = probe.ref_probe_raycaster(
+        os.path.join(REF, code_object).encode(), grid.ctypes.data_as(C.POINTER(C.c_int8)), (C.c_int32 * 3)(dim, dim, dim), w, h, _f(table),
+        (C.c_float * 2)(*[float(v) for v in s["cam_dir"]]), (C.c_float * 3)(*[float(v) for v in s["cam_pos"]]), _f(li), li.shape[0],
+        at.ctypes.data_as(C.POINTER(C.c_uint32)), (C.c_int32 * 2)(atlas.shape[1], atlas.shape[0]), (C.c_int32 * 2)(16, 16),
+        buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size, root, dim, 1, _i(rec), _f(trig))
+    assert rc == 0, probe.ref_probe_last_error().decode()
+    return rec, trig, buf, root
+
+
+@pytest.mark.parametrize("make", scenes.ALL, ids=[f.__name__ for f in scenes.ALL])
+@pytest.mark.parametrize("res", [(64, 48), (160, 120)], ids=["64x48", "160x120"])
+def test_reference_raycaster_step_loop_against_the_oracle(probe, make, res, atlas):
+    """SURVEY 8c G3 scenes (camera inside solid, pillars + shadows, mirror wall, rays leaving the map, axis-aligned rays
+    with unwritten pixels, random grid).  IEEE build of the reference kernel (no fast-math, no contraction, correctly
+    rounded / and sqrt): everything that depends only on the primary ray -- which voxel is hit, through which face,
+    after how many steps, with which material, which texel is fetched, whether the pixel is written at all -- must
+    equal the oracle EXACTLY.  What follows the shadow redirect goes through the OpenCL library's approximate
+    normalize / fast_distance (1-2 ulp, see view_light above), so the final step count and the colour are required
+    to agree on nearly all pixels and the rest is itemised."""
+    if not os.path.exists(os.path.join(REF, "ref_raycaster_gfx950_strict.co")):
+        pytest.skip("oracle/_ref/ref_raycaster_gfx950_strict.co not built (make -C oracle _ref)")
+    s, (w, h) = make(), res
+    rec, trig, buf, root = run_reference_raycaster(probe, "ref_raycaster_gfx950_strict.co", s, w, h, atlas)
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=s["lights"], atlas=atlas,
+                                    tile_dim=(16, 16), descriptors=buf, root_index=root, octree_dim=s["dim"], using_octree=1,
+                                    grid=s["grid"], max_distance=20, trig=trig)
+    written = rec[..., 15] == 1
+    # pixels the kernel returned from without writing (:293-294, :671-672, :694-695)
+    assert np.array_equal(written, (ohits[..., 5] & 1) == 1), "written / unwritten pixels differ"
+    assert octr["unwritten"] == int((~written).sum())
+    # the first solid hit of the primary ray: recorded at the kernel's first read_imagef (:652 / :684)
+    hit = rec[..., 16] > 0
+    assert np.array_equal(hit, ohits[..., 3] != 0), "which pixels hit something differs"
+    assert np.array_equal(rec[..., 17:20][hit], ohits[..., 0:3][hit]), "hit voxel"
+    face = rec[..., 20] | (rec[..., 21] << 1) | (rec[..., 22] << 2)
+    assert np.array_equal(face[hit], ohits[..., 4][hit]), "hit face"
+    assert np.array_equal(rec[..., 23][hit], ohits[..., 3][hit]), "hit material"
+    assert octr["n_tex"] == int(rec[..., 16].sum()), "texel fetches"
+    # rays that never hit anything: the whole ray is primary, so the end state is exact too
+    miss = written & ~hit
+    assert np.array_equal(rec[..., 11][miss], ohits[..., 6][miss]), "step count of rays that hit nothing"
+    fcol = rec[..., 0:4].view(np.float32)
+    assert np.array_equal(fcol[miss].view(np.uint32), oimg[miss].view(np.uint32)), "colour of rays that hit nothing"
+    # mirror bounces (:682-704)
+    assert np.array_equal(rec[..., 13][written], (ohits[..., 5][written] >> 4) & 3), "bounce count"
+    # after the shadow redirect: library normalize / fast_distance -> statistics, near-total agreement required
+    w_ = written & hit
+    if w_.any():
+        same_steps = rec[..., 11][w_] == ohits[..., 6][w_]
+        rel = np.abs(fcol[w_][:, :3] - oimg[w_][:, :3]) / np.maximum(np.abs(oimg[w_][:, :3]), 1e-6)
+        shadow_same = (rec[..., 12][w_] != 0) == ((ohits[..., 5][w_] & 2) != 0)
+        alpha_same = (np.abs(fcol[w_][:, 3] - oimg[w_][:, 3]) <= 1e-5 * np.maximum(np.abs(oimg[w_][:, 3]), 1e-6))
+        print(f"\n{s['name']} {w}x{h}: {int(w_.sum())} shaded pixels; final step count equal {same_steps.mean():.5f}, "
+              f"rgb within 1e-5 {float((rel.max(-1) <= 1e-5).mean()):.5f} (worst {float(rel.max()):.2e}), "
+              f"alpha (in-shadow flag) equal {alpha_same.mean():.5f}")
+        assert shadow_same.all()
+        assert same_steps.mean() >= 0.995 and alpha_same.mean() >= 0.995
+        assert (rel.max(-1) <= 1e-4).mean() >= 0.995
+
+
+def test_reference_raycaster_with_the_references_own_flags(probe, atlas):
+    """The same kernel built exactly as the reference application builds it (-cl-fast-relaxed-math
+    -cl-unsafe-math-optimizations -cl-finite-math-only, CLCaster.cpp:771): native divide / sin / cos and contraction
+    make bit equality with any IEEE form undefined, so this only itemises how far the reference's own GPU output is
+    from the oracle -- informational, asserted loosely."""
+    if not os.path.exists(os.path.join(REF, "ref_raycaster_gfx950.co")):
+        pytest.skip("oracle/_ref/ref_raycaster_gfx950.co not built")
+    lines = []
+    for make in scenes.ALL:
+        s, (w, h) = make(), (160, 120)
+        rec, trig, buf, root = run_reference_raycaster(probe, "ref_raycaster_gfx950.co", s, w, h, atlas)
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=s["lights"], atlas=atlas,
+                                     tile_dim=(16, 16), descriptors=buf, root_index=root, octree_dim=s["dim"], using_octree=1,
+                                     grid=s["grid"], max_distance=20, trig=trig)
+        hit = rec[..., 16] > 0
+        both = hit & (ohits[..., 3] != 0)
+        same_voxel = (rec[..., 17:20][both] == ohits[..., 0:3][both]).all(-1)
+        agree = float((hit == (ohits[..., 3] != 0)).mean())
+        lines.append(f"{s['name']}: hit/miss agreement {agree:.5f}, same hit voxel {float(same_voxel.mean()) if both.any() else 1.0:.5f}")
+        assert agree >= 0.99 and (not both.any() or same_voxel.mean() >= 0.99)
+    print("\n" + "\n".join(lines))

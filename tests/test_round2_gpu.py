@@ -1,0 +1,356 @@
+"""GPU suite (-m gpu), round 2: the device-side SVO builder and the real BASELINE configs[4] scene, row slices and
+the single-process multi-GPU group handle, the streamed upload against the oracle, the reference camera with its
+octree bias active, and the error paths the advisor asked for.  Everything goes through the C ABI (libvrc.so)."""
+import functools
+import os
+import resource
+import time
+
+import numpy as np
+import pytest
+
+import scenes
+import voxel_raycaster_amd as vrc
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@functools.lru_cache(maxsize=4)
+def bench_scene(depth):
+    import bench
+    return bench.build_scene(depth)
+
+
+def lights4(dim):
+    """L0..L3 at the quarter points, 3/4 up, all rgbi (0.01, 0.01, 0.01, 0.2); fractional offsets keep
+    shadow rays off exact voxel boundaries."""
+    li = np.zeros((8, 10), dtype=np.float32)
+    for l, (fx, fy) in enumerate(((0.25, 0.25), (0.75, 0.25), (0.25, 0.75), (0.75, 0.75))):
+        li[l] = [0.01, 0.01, 0.01, 0.2, fx * dim + 0.3 * l, fy * dim + 0.2 * l, 0.75 * dim + 0.1 * l, -1.0, -1.0, -1.5]
+    return li
+
+
+def configure(c, dim, atlas, cam_dir, cam_pos, lights, w, h, light_count=1, shadow_rays=1, table=None):
+    assert c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim)
+    assert c.add_to_settings_buffer("using_octree", "OCTENABLED", 0)
+    assert c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", 3 * dim)
+    assert c.add_to_settings_buffer("shadow_rays", "SHADOW_RAYS", shadow_rays)
+    assert c.add_to_settings_buffer("light_count", "LIGHT_COUNT", light_count)
+    cd, cp = np.array(cam_dir, dtype=np.float32), np.array(cam_pos, dtype=np.float32)
+    assert c.assign_camera(cd, cp)
+    assert c.create_viewport(w, h) if table is None else c.create_viewport_table(table)
+    assert c.assign_lights(lights)
+    assert c.create_texture_atlas(atlas, (16, 16))
+    c._li = lights
+    return c
+
+
+def survey_camera(depth, seed=1, thickness=2, octave_floor=2):
+    """SURVEY 8d's camera exactly as written: (D/2 + 0.37, D/8 + 0.41, h(D/2, D/8) + D/16 + 0.29), looking
+    (inclination 2.0, azimuth 1.5708); no search for a voxel whose octree bias is zero."""
+    dim = 1 << depth
+    _, hi = vrc.shell_column(depth, dim // 2, dim // 8, seed=seed, thickness=thickness, octave_floor=octave_floor)
+    return (2.0, 1.5708), (dim / 2 + 0.37, dim / 8 + 0.41, hi + dim // 16 + 0.29)
+
+
+# ------------------------------------------------------------------ device builder
+@pytest.mark.parametrize("depth,thickness,floor", [(3, 2, 2), (5, 2, 2), (6, 0, 2), (7, 3, 0), (8, 2, 2), (9, 7, 1), (10, 2, 2), (12, 2, 2)])
+def test_device_builder_equals_host_builder(depth, thickness, floor):
+    """vrc_build_shell_terrain: the array built in HBM is bit-identical to the sequential host emitter's brick
+    layout, Octree::Validate on the device finds no mismatch, and the device height field equals the procedural
+    column function."""
+    dim = 1 << depth
+    host, _ = vrc.shell_terrain_ex(depth, seed=1, thickness=thickness, octave_floor=floor, layout=vrc.LAYOUT_NO_PAGE_HEADERS)
+    c = vrc.CLCaster()
+    assert c.init(0)
+    rng = np.random.default_rng(depth)
+    probe = rng.integers(0, dim, size=(64, 2)).astype(np.int32)
+    counted, _ = c.build_shell_terrain(depth, 1, thickness, floor, count_only=True)
+    assert counted["n_descriptors"] == host.descriptor_buffer.size
+    info, lohi = c.build_shell_terrain(depth, 1, thickness, floor, validate_samples=1 << 20, probe_xy=probe)
+    assert info["n_descriptors"] == host.descriptor_buffer.size and info["root_index"] == host.root_index
+    assert info["validate_samples"] == 1 << 20 and info["validate_mismatches"] == 0
+    assert c.octree_size() == (host.descriptor_buffer.size, host.root_index)
+    dev = c.read_descriptors()
+    assert np.array_equal(dev, host.descriptor_buffer), f"{int((dev != host.descriptor_buffer).sum())} slots differ"
+    for (x, y), (lo, hi) in zip(probe, lohi):
+        assert (lo, hi) == vrc.shell_column(depth, x, y, seed=1, thickness=thickness, octave_floor=floor)
+
+
+def test_device_built_scene_renders_like_the_oracle(atlas):
+    """A frame of a device-built tree (depth 9, thick shell, survey camera with the octree bias active) against the
+    oracle rendering the host-built paged-layout tree of the same scene: the layout never shows in the picture."""
+    depth, thickness, w, h = 9, 6, 320, 200
+    dim = 1 << depth
+    cam_dir, cam_pos = survey_camera(depth, thickness=thickness)
+    c = vrc.CLCaster()
+    assert c.init(0)
+    c.build_shell_terrain(depth, 1, thickness, 2)
+    configure(c, dim, atlas, cam_dir, cam_pos, lights4(dim), w, h, light_count=2)
+    assert c.validate() and c.compute(), c.last_error()
+    host, _ = vrc.shell_terrain_ex(depth, thickness=thickness)     # the reference-style paged layout
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas, tile_dim=(16, 16),
+                                    descriptors=host.descriptor_buffer, root_index=host.root_index, octree_dim=dim,
+                                    using_octree=0, max_distance=3 * dim, active_lights=2, threads=8)
+    assert np.array_equal(c.read_hits(), ohits)
+    assert np.array_equal(c.read_image().view(np.uint32), oimg.view(np.uint32))
+    ctr = c.counters()
+    assert ctr["descriptor_reads"] == octr["n_desc"] and ctr["steps"] == octr["n_steps"]
+
+
+def test_configs4_scene_200GB_resident_sampled_rows(atlas):
+    """BASELINE configs[4]: 65536^3 (depth 16) sparse SVO, >= 2e10 descriptors (~190 GB) resident in HBM, built on the
+    device in seconds with a few MB of host memory; 7680x4320, 4 lights.  Octree::Validate on the device over 2^28
+    voxels, sampled columns against the procedural scene function, and sampled rows of the frame bit-exact against
+    the oracle, which reads the descriptors it needs from the GPU page by page."""
+    depth, thickness, floor, w, h = 16, int(os.environ.get("VRC_C5_THICKNESS", "33")), 2, 7680, 4320
+    dim = 1 << depth
+    c = vrc.CLCaster()
+    assert c.init(0)
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    rng = np.random.default_rng(16)
+    probe = rng.integers(0, dim, size=(256, 2)).astype(np.int32)
+    t0 = time.perf_counter()
+    info, lohi = c.build_shell_terrain(depth, 1, thickness, floor, validate_samples=1 << 28, probe_xy=probe)
+    wall = time.perf_counter() - t0
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    print(f"\nconfigs[4] scene: {info['n_descriptors'] / 1e9:.2f} G descriptors = {info['n_descriptors'] * 8 / 1e9:.1f} GB in HBM, "
+          f"{info['n_bricks']} bricks, built in {wall:.1f} s (height {info['seconds_height']:.2f} count {info['seconds_count']:.2f} "
+          f"emit {info['seconds_emit']:.2f}), host tables {info['host_bytes'] / 1e6:.0f} MB, process max RSS {rss1 / 1e6:.2f} GB "
+          f"(+{(rss1 - rss0) / 1e6:.2f} GB during the build), device peak {info['device_bytes_peak'] / 1e9:.1f} GB")
+    assert info["n_descriptors"] >= 20_000_000_000
+    assert info["validate_mismatches"] == 0 and info["validate_samples"] == 1 << 28
+    assert wall < 60.0 and rss1 < 16e6                               # ru_maxrss is in kB
+    for (x, y), (lo, hi) in zip(probe, lohi):
+        assert (lo, hi) == vrc.shell_column(depth, x, y, seed=1, thickness=thickness, octave_floor=floor)
+
+    cam_dir, cam_pos = survey_camera(depth, thickness=thickness, octave_floor=floor)
+    configure(c, dim, atlas, cam_dir, cam_pos, lights4(dim), w, h, light_count=4)
+    assert c.validate() and c.compute(), c.last_error()
+    n_launch, ms = c.timing()
+    ctr = c.counters()
+    print(f"configs[4] frame on one GPU: {ms / n_launch:.1f} ms, {ctr['primary_rays'] + ctr['shadow_rays']} rays, "
+          f"{ctr['steps'] / 1e9:.1f} G steps, {ctr['descriptor_reads'] / 1e6:.1f} M descriptor reads")
+    assert ctr["primary_rays"] == w * h and ctr["shadow_rays"] > w * h
+    img, hits = c.read_image(), c.read_hits()
+    assert ctr["descriptor_reads"] == int(hits[..., 7].astype(np.int64).sum())
+    n, root = c.octree_size()
+    paged = orc.PagedDescriptors(n, c.read_descriptors)
+    threads = max(1, min(32, len(os.sched_getaffinity(0))))
+    t0 = time.perf_counter()
+    for y0 in (613, 2160, 3707):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas, tile_dim=(16, 16),
+                                     descriptors=paged, root_index=root, octree_dim=dim, using_octree=0, max_distance=3 * dim,
+                                     rows=(y0, y0 + 1), threads=threads, active_lights=4)
+        assert np.array_equal(hits[y0], ohits[y0]), f"row {y0}: {int((hits[y0] != ohits[y0]).any(-1).sum())} pixels differ"
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+    print(f"oracle: 3 rows in {time.perf_counter() - t0:.1f} s on {threads} threads, {paged.bytes_fetched / 1e6:.0f} MB of descriptors fetched")
+
+
+# ------------------------------------------------------------------ reference camera, bias active
+def test_headline_size_frame_with_the_reference_bias_active(atlas):
+    """BASELINE-size frame (depth 12, 1920x1080) from SURVEY 8d's camera as written, where the reference's
+    intersection_t bias (ray_caster_kernel.cl:353-354) is not zero: sampled rows bit-exact vs the oracle."""
+    depth, w, h = 12, 1920, 1080
+    dim = 1 << depth
+    sc = bench_scene(depth)
+    cam_dir, cam_pos = survey_camera(depth)
+    found, res, sub = sc["octree"].GetVoxel(tuple(int(np.floor(v)) for v in cam_pos))
+    bias = [(s - int(np.floor(v))) * res // 2 for s, v in zip(sub, cam_pos)]
+    assert not found and any(b != 0 for b in bias), "this camera must exercise the bias term"
+    c = vrc.CLCaster()
+    assert c.init(0) and c.assign_octree(sc["octree"])
+    configure(c, dim, atlas, cam_dir, cam_pos, sc["lights"], w, h)
+    assert c.validate() and c.compute(), c.last_error()
+    img, hits = c.read_image(), c.read_hits()
+    for y0 in range(11, h, 97):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas, tile_dim=(16, 16),
+                                     descriptors=sc["octree"].descriptor_buffer, root_index=sc["octree"].root_index, octree_dim=dim,
+                                     using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=16)
+        assert np.array_equal(hits[y0], ohits[y0])
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+    # and it is not the frame the unbiased kernel renders
+    assert c.add_to_settings_buffer("octree_bias", "OCTREE_BIAS", 0) and c.compute()
+    assert not np.array_equal(c.read_hits()[540], hits[540])
+
+
+# ------------------------------------------------------------------ row slices and the group handle
+def test_row_slices_hold_only_their_rows_and_assemble_the_frame(atlas):
+    s = scenes.random_sparse()
+    dim, w, h = s["dim"], 200, 123                                  # ragged: last band partial, last tile row partial
+    m = vrc.Map(dim, s["grid"])
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = s["lights"]
+    full = vrc.CLCaster()
+    assert full.init(0) and full.assign_octree(m.octree)
+    configure(full, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
+    assert full.validate() and full.compute()
+    ref_img, ref_hits, ref_rgba, ref_ctr = full.read_image(), full.read_hits(), full.read_image_rgba8(), full.counters()
+    for world, band in [(2, 8), (3, 16), (4, 8)]:
+        img = np.full((h, w, 4), -7.0, dtype=np.float32)
+        hits = np.full((h, w, 8), -7, dtype=np.int32)
+        rgba = np.full((h, w, 4), 77, dtype=np.uint8)
+        rays, rows_seen = 0, 0
+        for r in range(world):
+            c = vrc.CLCaster()
+            assert c.init(0) and c.set_row_slice(r, world, band) and c.assign_octree(m.octree)
+            configure(c, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
+            assert c.set_row_slice(r, world, band) is False          # the buffers are already sized
+            assert c.validate() and c.compute(), c.last_error()
+            mem = c.memory_usage()
+            from voxel_raycaster_amd import tiling
+            mine = tiling.rows_of_rank(h, r, world, band)
+            assert mem["rows"] == len(mine) and mem["viewport_bytes"] == 16 * w * len(mine) == mem["image_bytes"]
+            assert mem["hit_bytes"] == 32 * w * len(mine)
+            c.read_image(img); c.read_hits(hits); c.read_image_rgba8(rgba)
+            rays += c.counters()["primary_rays"]
+            rows_seen += len(mine)
+        assert rows_seen == h and rays == ref_ctr["primary_rays"]
+        assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)) and np.array_equal(hits, ref_hits)
+        assert np.array_equal(rgba, ref_rgba)
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_group_handle_is_one_synchronous_compute_over_all_ranks(ranks, atlas):
+    """vrc_create_group with every rank on GPU 0 (all this box has): one compute() renders all row slices, the
+    read-back gathers them, counters are summed, each rank holds 1/n of the frame buffers and shares rank 0's tree."""
+    sc = bench_scene(10)
+    dim, w, h = sc["dim"], 1280, 720
+    one = vrc.CLCaster()
+    assert one.init(0) and one.assign_octree(sc["octree"])
+    configure(one, dim, sc["atlas"], sc["cam_dir"], sc["cam_pos"], sc["lights"], w, h)
+    assert one.validate() and one.compute()
+    g = vrc.CLCaster()
+    assert g.init_group([0] * ranks, band_rows=8) and g.group_size() == ranks
+    assert g.assign_octree(sc["octree"])
+    configure(g, dim, sc["atlas"], sc["cam_dir"], sc["cam_pos"], sc["lights"], w, h)
+    assert g.set_row_tiling(0, 1, 8) is False                       # a group's tiling is fixed
+    assert g.validate() and g.compute(), g.last_error()
+    assert np.array_equal(g.read_image().view(np.uint32), one.read_image().view(np.uint32))
+    assert np.array_equal(g.read_hits(), one.read_hits()) and np.array_equal(g.read_image_rgba8(), one.read_image_rgba8())
+    assert g.counters() == one.counters()
+    rows = [g.memory_usage(r) for r in range(ranks)]
+    assert sum(m["rows"] for m in rows) == h and all(m["image_bytes"] == 16 * w * m["rows"] for m in rows)
+    assert rows[0]["octree_shared"] == 0 and all(m["octree_shared"] == 1 for m in rows[1:])
+    # live settings and live camera reach every rank
+    cam = g._keep["cam"][1]
+    cam[2] += 3.0
+    one._keep["cam"][1][2] += 3.0
+    assert g.overwrite_setting("shadow_rays", 0) and one.overwrite_setting("shadow_rays", 0)
+    assert g.compute() and one.compute()
+    assert np.array_equal(g.read_image().view(np.uint32), one.read_image().view(np.uint32))
+    # a device-built tree fans out too
+    info, _ = g.build_shell_terrain(10, 1, 2, 2)
+    assert g.validate() and g.compute(), g.last_error()
+    assert g.octree_size()[0] == info["n_descriptors"] and g.counters()["primary_rays"] == w * h
+
+
+# ------------------------------------------------------------------ streamed upload vs the ORACLE
+@pytest.mark.parametrize("depth,chunk", [(10, 1 << 20), (12, 64 << 20), (13, 64 << 20)], ids=["d10-1MB-chunks", "d12-3-chunks", "d13-11-chunks"])
+def test_streamed_upload_multi_chunk_against_the_oracle(depth, chunk, tmp_path):
+    """vrc_assign_octree_file with trees that need many staging-buffer cycles (depth 12: 161 MB, depth 13: 674 MB with
+    far pointers) and attachments (mirrors every 64th voxel): sampled rows bit-exact vs the oracle on the in-memory
+    arrays."""
+    sc = bench_scene(depth)
+    dim, w, h = sc["dim"], 1024, 576
+    tree = sc["octree"]
+    if tree.attachment_lookup is None:
+        tree.attach_materials_procedural(depth, seed=1, mirror_period=64)
+    path = str(tmp_path / "scene.svo")
+    tree.Save(path)
+    assert os.path.getsize(path) > 2 * chunk
+    c = vrc.CLCaster()
+    assert c.init(0)
+    assert c.add_to_settings_buffer("upload_chunk_bytes", "UPLOAD_CHUNK_BYTES", chunk)
+    assert c.assign_octree_file(path) == dim, c.last_error()
+    os.remove(path)
+    configure(c, dim, sc["atlas"], sc["cam_dir"], sc["cam_pos"], sc["lights"], w, h)
+    assert c.validate() and c.compute(), c.last_error()
+    img, hits = c.read_image(), c.read_hits()
+    assert (hits[..., 3] == 6).sum() > 100                          # mirrors came through the file
+    for y0 in range(5, h, 57):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=c._li, atlas=sc["atlas"],
+                                     tile_dim=(16, 16), descriptors=tree.descriptor_buffer, root_index=tree.root_index, octree_dim=dim,
+                                     using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=16,
+                                     attachment_lookup=tree.attachment_lookup, attachments=tree.attachment_buffer)
+        assert np.array_equal(hits[y0], ohits[y0])
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+
+
+# ------------------------------------------------------------------ advisor findings
+def test_a_new_tree_never_inherits_the_old_trees_materials(atlas):
+    """vrc_assign_octree after a tree with attachments: the material buffers of the old tree are gone (they are indexed
+    by the old tree's descriptor indices)."""
+    from test_oracle_cpu import _with_pass_through
+    s = _with_pass_through(scenes.mirror_wall())
+    dim, w, h = s["dim"], 128, 96
+    with_mat = vrc.Octree.Generate(s["grid"], dim).attach_materials_from_grid(s["grid"])
+    t = scenes.random_sparse()
+    tdim = t["dim"]
+    bigger = vrc.Octree.Generate(t["grid"], tdim)                   # another, larger tree without attachments
+    assert bigger.descriptor_buffer.size > with_mat.descriptor_buffer.size
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = t["lights"]
+    c = vrc.CLCaster()
+    assert c.init(0) and c.assign_octree(with_mat)
+    configure(c, dim, atlas, t["cam_dir"], t["cam_pos"], li, w, h)
+    assert c.validate() and c.compute()
+    assert c.assign_octree(bigger) and c.overwrite_setting("octree_dimensions", tdim) and c.overwrite_setting("max_distance", 3 * tdim)
+    assert c.validate() and c.compute(), c.last_error()
+    oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=t["cam_dir"], cam_pos=t["cam_pos"], lights=li, atlas=atlas, tile_dim=(16, 16),
+                                 descriptors=bigger.descriptor_buffer, root_index=bigger.root_index, octree_dim=tdim, using_octree=0,
+                                 max_distance=3 * tdim)
+    assert np.array_equal(c.read_hits(), ohits) and np.array_equal(c.read_image().view(np.uint32), oimg.view(np.uint32))
+    bad = with_mat.attachment_lookup.copy()
+    bad[5] = with_mat.attachment_buffer.size + 3
+    import ctypes as C
+    assert c.assign_octree(with_mat) and c.overwrite_setting("octree_dimensions", dim)
+    rc = vrc.lib.vrc_assign_octree_attachments(c._h, bad.ctypes.data_as(C.POINTER(C.c_uint32)), bad.size,
+                                               with_mat.attachment_buffer.ctypes.data_as(C.POINTER(C.c_uint64)), with_mat.attachment_buffer.size)
+    assert rc == 1 and "past the attachment buffer" in c.last_error()
+
+
+def test_live_settings_are_rechecked_by_every_compute(atlas):
+    """Settings stay live after validate(); a structural setting changed to nonsense makes compute() return an error
+    code, never a device fault."""
+    s = scenes.floor_pillars()
+    dim, w, h = s["dim"], 96, 64
+    m = vrc.Map(dim, s["grid"])
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = s["lights"]
+    c = vrc.CLCaster()
+    assert c.init(0) and c.assign_octree(m.octree)
+    configure(c, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
+    assert c.validate() and c.compute()
+    good = c.read_image()
+    for name, value, word in [("octree_dimensions", 3, "power of two"), ("octree_dimensions", 1 << 30, "power of two"),
+                              ("octree_root_index", 10 ** 9, "out of range"), ("using_octree", 1, "dense map"),
+                              ("stepping_mode", 7, "stepping_mode")]:
+        old = c.get_setting(name)
+        if old is None:
+            assert c.add_to_settings_buffer(name, name.upper(), value)
+            old = 0
+        else:
+            assert c.overwrite_setting(name, value)
+        assert c.compute() is False and c.last_status in (1, 2) and word in c.last_error(), (name, c.last_error())
+        assert c.overwrite_setting(name, old) and c.compute()
+    assert np.array_equal(c.read_image().view(np.uint32), good.view(np.uint32))
+
+
+def test_hit_records_can_be_switched_off(atlas):
+    s = scenes.floor_pillars()
+    dim, w, h = s["dim"], 128, 96
+    m = vrc.Map(dim, s["grid"])
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = s["lights"]
+    c = vrc.CLCaster()
+    assert c.init(0) and c.assign_octree(m.octree)
+    configure(c, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
+    assert c.add_to_settings_buffer("hit_records", "HIT_RECORDS", 0) and c.validate() and c.compute()
+    assert c.memory_usage()["hit_bytes"] == 0
+    with pytest.raises(vrc.VrcError):
+        c.read_hits()
+    img = c.read_image()
+    assert c.overwrite_setting("hit_records", 1) and c.compute()
+    assert np.array_equal(c.read_image().view(np.uint32), img.view(np.uint32)) and c.read_hits()[..., 3].max() == 5

@@ -41,6 +41,23 @@ _i8p = C.POINTER(C.c_int8)
 _H = C.c_void_p
 
 
+class BuildInfo(C.Structure):
+    _fields_ = ([(n, C.c_uint64) for n in ("n_descriptors", "root_index", "n_bricks", "n_top_slots", "n_far_pointers_top")]
+                + [(n, C.c_double) for n in ("seconds_total", "seconds_height", "seconds_count", "seconds_emit")]
+                + [(n, C.c_uint64) for n in ("device_bytes_peak", "host_bytes", "validate_samples", "validate_mismatches")])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Memory(C.Structure):
+    _fields_ = [("device", C.c_int32), ("rows", C.c_int32), ("viewport_bytes", C.c_uint64), ("image_bytes", C.c_uint64),
+                ("hit_bytes", C.c_uint64), ("octree_bytes", C.c_uint64), ("octree_shared", C.c_int32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "primary_rays", "shadow_rays", "descriptor_reads", "texel_reads", "map_reads", "steps",
@@ -99,7 +116,20 @@ SIGNATURES = {
     "vrc_assign_octree_file": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_uint32)]),
     "vrc_scene_diamond_square": (C.c_int, [C.c_uint32, C.c_double, _u8p, _i8p]),
     "vrc_free": (None, [C.c_void_p]),
+    "vrc_set_row_slice": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32]),
+    "vrc_create_group": (C.c_int, [_i32p, C.c_int32, C.c_int32, C.POINTER(_H)]),
+    "vrc_group_size": (C.c_int, [_H, _i32p]),
+    "vrc_pin_host_buffer": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "vrc_unpin_host_buffer": (C.c_int, [C.c_void_p]),
+    "vrc_memory_usage": (C.c_int, [_H, C.c_int32, C.POINTER(Memory)]),
+    "vrc_scene_shell_terrain_ex": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(_u64p), _u64p, _u64p, _i32p]),
+    "vrc_scene_shell_column": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _i32p, _i32p]),
+    "vrc_build_shell_terrain": (C.c_int, [_H, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint32, C.c_uint64, _i32p, C.c_uint32,
+                                          _i32p, C.POINTER(BuildInfo)]),
+    "vrc_read_descriptors": (C.c_int, [_H, C.c_uint64, C.c_uint64, _u64p]),
+    "vrc_octree_size": (C.c_int, [_H, _u64p, _u64p]),
 }
+LAYOUT_STRICT_REFERENCE, LAYOUT_NO_PAGE_HEADERS, BUILD_COUNT_ONLY = 1, 2, 1
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)
     _fn.restype = _res
@@ -225,6 +255,30 @@ def shell_terrain(depth: int, seed: int = 1, thickness: int = 2, strict_referenc
     return Octree(arr, root.value, dim), height
 
 
+def shell_terrain_ex(depth: int, seed: int = 1, thickness: int = 2, octave_floor: int = 2, layout: int = 0,
+                     want_height: bool = False):
+    """vrc_scene_shell_terrain_ex: the scene with its knobs exposed (layout = LAYOUT_* flags)."""
+    dim = 1 << depth
+    out, n, root = _u64p(), C.c_uint64(), C.c_uint64()
+    height = np.zeros((dim, dim), dtype=np.int32) if want_height else None
+    rc = lib.vrc_scene_shell_terrain_ex(depth, seed, thickness, octave_floor, layout, C.byref(out), C.byref(n), C.byref(root),
+                                        _ptr(height, _i32p) if want_height else None)
+    if rc != 0:
+        raise VrcError(f"vrc_scene_shell_terrain_ex: {STATUS.get(rc, rc)}")
+    arr = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
+    lib.vrc_free(out)
+    return Octree(arr, root.value, dim), height
+
+
+def shell_column(depth: int, x: int, y: int, seed: int = 1, thickness: int = 2, octave_floor: int = 2):
+    """(lo, hi) of one column of the scene, evaluated procedurally: solid for lo <= z <= hi."""
+    lo, hi = C.c_int32(), C.c_int32()
+    rc = lib.vrc_scene_shell_column(depth, seed, thickness, octave_floor, int(x), int(y), C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise VrcError(f"vrc_scene_shell_column: {STATUS.get(rc, rc)}")
+    return int(lo.value), int(hi.value)
+
+
 def shell_terrain_dense(depth: int, seed: int = 1, thickness: int = 2) -> np.ndarray:
     dim = 1 << depth
     grid = np.zeros(dim ** 3, dtype=np.int8)
@@ -297,6 +351,53 @@ class CLCaster:
     # -- CLCaster::init (CLCaster.cpp:14-74)
     def init(self, device_ordinal: int = 0) -> bool:
         return self._ok(lib.vrc_create(device_ordinal, C.byref(self._h)))
+
+    def init_group(self, device_ordinals, band_rows: int = 8) -> bool:
+        """One host thread, several GPUs (vrc_create_group): this object becomes rank 0 of a row-sliced group."""
+        d = np.ascontiguousarray(device_ordinals, dtype=np.int32)
+        return self._ok(lib.vrc_create_group(_ptr(d, _i32p), d.size, band_rows, C.byref(self._h)))
+
+    def group_size(self) -> int:
+        n = C.c_int32()
+        lib.vrc_group_size(self._h, C.byref(n))
+        return int(n.value)
+
+    def memory_usage(self, rank: int = 0) -> dict:
+        m = Memory()
+        if not self._ok(lib.vrc_memory_usage(self._h, rank, C.byref(m))):
+            raise VrcError(self.last_error())
+        return m.as_dict()
+
+    def build_shell_terrain(self, depth: int, seed: int = 1, thickness: int = 2, octave_floor: int = 2, count_only: bool = False,
+                            validate_samples: int = 0, probe_xy: Optional[np.ndarray] = None):
+        """vrc_build_shell_terrain: the scene's SVO built in HBM.  Returns (info dict, probe lo/hi array or None);
+        raises on failure."""
+        info = BuildInfo()
+        pxy = plh = None
+        if probe_xy is not None:
+            pxy = np.ascontiguousarray(probe_xy, dtype=np.int32).reshape(-1, 2)
+            plh = np.zeros_like(pxy)
+        rc = lib.vrc_build_shell_terrain(self._h, depth, seed, thickness, octave_floor, BUILD_COUNT_ONLY if count_only else 0,
+                                         validate_samples, _ptr(pxy, _i32p) if pxy is not None else None,
+                                         0 if pxy is None else pxy.shape[0], _ptr(plh, _i32p) if plh is not None else None,
+                                         C.byref(info))
+        if not self._ok(rc):
+            raise VrcError(self.last_error())
+        return info.as_dict(), plh
+
+    def octree_size(self):
+        n, root = C.c_uint64(), C.c_uint64()
+        if not self._ok(lib.vrc_octree_size(self._h, C.byref(n), C.byref(root))):
+            raise VrcError(self.last_error())
+        return int(n.value), int(root.value)
+
+    def read_descriptors(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        if count is None:
+            count = self.octree_size()[0] - first
+        out = np.empty(count, dtype=np.uint64)
+        if not self._ok(lib.vrc_read_descriptors(self._h, first, count, _ptr(out, _u64p))):
+            raise VrcError(self.last_error())
+        return out
 
     # -- scene
     def assign_map(self, map_: "Map | np.ndarray", dims=None) -> bool:
@@ -402,24 +503,32 @@ class CLCaster:
     def set_row_tiling(self, rank: int, world: int, band_rows: int = 8) -> bool:
         return self._ok(lib.vrc_set_row_tiling(self._h, rank, world, band_rows))
 
+    def set_row_slice(self, rank: int, world: int, band_rows: int = 8) -> bool:
+        """Like set_row_tiling, but the buffers hold only this rank's rows (call before create_viewport)."""
+        return self._ok(lib.vrc_set_row_slice(self._h, rank, world, band_rows))
+
     # -- output (replaces CLCaster::draw, CLCaster.cpp:330-332)
-    def read_image(self) -> np.ndarray:
+    def read_image(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """The float4 frame.  A row-sliced handle fills only its own rows of `out` (pass the same array to every rank)."""
         w, h = self.viewport_size
-        out = np.empty((h, w, 4), dtype=np.float32)
+        if out is None:
+            out = np.empty((h, w, 4), dtype=np.float32)
         if not self._ok(lib.vrc_read_image_f32(self._h, _ptr(out, _f32p), out.size)):
             raise VrcError(self.last_error())
         return out
 
-    def read_image_rgba8(self) -> np.ndarray:
+    def read_image_rgba8(self, out: Optional[np.ndarray] = None) -> np.ndarray:
         w, h = self.viewport_size
-        out = np.empty((h, w, 4), dtype=np.uint8)
+        if out is None:
+            out = np.empty((h, w, 4), dtype=np.uint8)
         if not self._ok(lib.vrc_read_image_rgba8(self._h, _ptr(out, _u8p), out.size)):
             raise VrcError(self.last_error())
         return out
 
-    def read_hits(self) -> np.ndarray:
+    def read_hits(self, out: Optional[np.ndarray] = None) -> np.ndarray:
         w, h = self.viewport_size
-        out = np.empty((h, w, 8), dtype=np.int32)
+        if out is None:
+            out = np.empty((h, w, 8), dtype=np.int32)
         if not self._ok(lib.vrc_read_hits(self._h, _ptr(out, _i32p), out.size)):
             raise VrcError(self.last_error())
         return out

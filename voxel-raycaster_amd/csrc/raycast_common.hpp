@@ -278,6 +278,7 @@ __device__ __forceinline__ void ray_finish(Ray &r, const RaycastParams &p, long 
                         mix_cl(0.0f, r.color_accumulator[2], k), mix_cl(0.0f, r.color_accumulator[3], k));
         r.flags |= kFlagWritten;
     }
+    if (!p.hits) return;
     int4 *hp = reinterpret_cast<int4 *>(p.hits) + 2 * pix;
     hp[0] = make_int4(r.hit_vx, r.hit_vy, r.hit_vz, r.hit_mat);
     hp[1] = make_int4(r.hit_face, r.flags | ((int)(r.bounce_count & 3) << 4), r.distance_traveled, (int)c_desc);
@@ -287,7 +288,7 @@ __device__ __forceinline__ void ray_finish(Ray &r, const RaycastParams &p, long 
 // the row count is a multiple of 8 and otherwise keeps the row-major order (XCD k gets every 8th block of each row);
 // either way every XCD renders the same sky/ground mix.  xcd_mode 0 gives XCD k the k-th contiguous eighth of the
 // image (L2 locality, but 37 % slower: sky rows take longer than ground rows); xcd_mode 2 never remaps.
-__device__ __forceinline__ void block_pixel(const RaycastParams &p, int &px, int &py) {
+__device__ __forceinline__ void block_pixel(const RaycastParams &p, int &px, int &py, int &buffer_row) {
     const int nblocks = gridDim.x;
     int bid = blockIdx.x;
     const int per_xcd = nblocks >> 3;
@@ -308,6 +309,8 @@ __device__ __forceinline__ void block_pixel(const RaycastParams &p, int &px, int
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     px = (bx * kTilesPerBlock + wave) * kTileW + (lane & (kTileW - 1));
     py = tile_y * kTileH + lane / kTileW;
+    // row of this pixel in the viewport / image / hit buffers: the image row, or its position among this rank's rows
+    buffer_row = p.row_sliced ? local_ty * kTileH + lane / kTileW : py;
 }
 
 // per-block counter partials (no global atomics): wave shuffle reduce, LDS, one row per block

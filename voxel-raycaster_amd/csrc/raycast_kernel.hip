@@ -55,12 +55,12 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
     if (threadIdx.x < kCtrCount) block_ctr[threadIdx.x] = 0;
     __syncthreads();
 
-    int px, py;
-    block_pixel(p, px, py);
+    int px, py, brow;
+    block_pixel(p, px, py, brow);
     unsigned c_primary = 0, c_desc = 0, c_map = 0, c_steps = 0, c_unwritten = 0, c_tex = 0, c_shadow = 0;
 
     if (px < p.width && py < p.height) {
-        const long pix = (long)px + (long)p.width * py;
+        const long pix = (long)px + (long)p.width * brow;
         Ray r;
         if (!ray_setup(r, p, pix)) {
             c_unwritten = 1;
@@ -124,10 +124,10 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
     if (tid < kCtrCount) block_ctr[tid] = 0;
     __syncthreads();
 
-    int px, py;
-    block_pixel(p, px, py);
+    int px, py, brow;
+    block_pixel(p, px, py, brow);
     const bool in_image = px < p.width && py < p.height;
-    const long pix = (long)px + (long)p.width * py;
+    const long pix = (long)px + (long)p.width * brow;
 
     Ray r;
     unsigned c_primary = 0, c_desc = 0, c_unwritten = 0, broke = 0;
@@ -515,7 +515,10 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         }
     }
 
-    if (rounds_left < 0 && (tid & 63) == 0) atomicAdd(&block_ctr[kCtrWatchdog], 1ULL);
+    if (rounds_left < 0 && (tid & 63) == 0) {
+        atomicAdd(&block_ctr[kCtrWatchdog], 1ULL);
+        if (p.watchdog_flag) __hip_atomic_store(p.watchdog_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     unsigned c_steps = 0, c_tex = 0, c_shadow = 0;
     if (in_image) {
         if (c_primary) {
@@ -583,14 +586,49 @@ __global__ void frame_setup_kernel(const RaycastParams p) {
     p.frame[3] = reads;
 }
 
+// the image the reference starts from: RGBA8 (255,255,255,100) (CLCaster.cpp:280-286) as normalised floats
+__global__ void fill_image_kernel(float4 *image, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) image[i] = make_float4(1.0f, 1.0f, 1.0f, 100.0f / 255.0f);
+}
+
+// write_imagef to the reference's CL_UNORM_INT8 target (CLCaster.cpp:278-296): saturate, scale, round to nearest even
+__global__ void pack_rgba8_kernel(const float4 *__restrict__ image, uchar4 *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = image[i];
+    auto q = [](float f) -> unsigned char {
+        if (!(f > 0.0f)) f = 0.0f;                        // NaN and negatives saturate to 0
+        if (f > 1.0f) f = 1.0f;
+        return (unsigned char)__float2int_rn(f * 255.0f);
+    };
+    out[i] = make_uchar4(q(v.x), q(v.y), q(v.z), q(v.w));
+}
+
+hipError_t launch_fill_image(float *image, size_t n_pixels, hipStream_t stream) {
+    if (!n_pixels) return hipSuccess;
+    hipLaunchKernelGGL(fill_image_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<float4 *>(image), n_pixels);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_rgba8(const float *image, uint8_t *out, size_t n_pixels, hipStream_t stream) {
+    if (!n_pixels) return hipSuccess;
+    hipLaunchKernelGGL(pack_rgba8_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4 *>(image), reinterpret_cast<uchar4 *>(out), n_pixels);
+    return hipGetLastError();
+}
+
 hipError_t launch_frame_setup(const RaycastParams &p, hipStream_t stream) {
     hipLaunchKernelGGL(frame_setup_kernel, dim3(1), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 
+hipError_t launch_raycast_jump(const RaycastParams &p, hipStream_t stream);   // raycast_jump_kernel.hip
+
 hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
     const int nblocks = p.blocks_x * p.local_tile_rows;
     if (nblocks <= 0) return hipSuccess;
+    if (p.svo && p.stepping_mode == 1) return launch_raycast_jump(p, stream);
     if (p.svo) {
         const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
         const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t) + (size_t)p.lds_pad_bytes;

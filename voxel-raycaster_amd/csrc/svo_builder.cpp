@@ -23,8 +23,11 @@
 #include <vector>
 
 #include "../../include/vrc.h"
+#include "shell_scene.hpp"
 
 namespace {
+using vrc::lattice;
+using vrc::splitmix64;
 
 constexpr uint64_t kFarBit = 0x8000ULL;
 constexpr uint64_t kLeafAll = 0xFF000000ULL;
@@ -43,13 +46,16 @@ inline bool is_empty_leaf(uint64_t d) {
 
 class Emitter {
 public:
-    explicit Emitter(bool strict) : strict_(strict) {}
+    // pages = false: the "brick" layout of the streamed / device builders (svo_builder_gpu.hip): same descriptor
+    // format and the same bottom-up order, but no page-header slots, so the size of a subtree does not depend on
+    // where it lands and subtrees can be counted and emitted independently
+    explicit Emitter(bool strict, bool pages = true) : strict_(strict), pages_(pages) {}
 
     // Places the kept children of one node; returns the reversed coordinate of
     // the node's child block (Octree.cpp:245-319).
     int64_t place(const Node *kept, int n) {
         const int worst = 2 * n;
-        if (page_counter_ - worst <= 0) {                 // page header (:252-262)
+        if (pages_ && page_counter_ - worst <= 0) {       // page header (:252-262)
             skip(page_counter_);
             page_counter_ = 0x8000;
             push(~0ULL);
@@ -122,7 +128,7 @@ private:
     std::vector<uint64_t> rev_;
     std::vector<int64_t> far_fixups_;
     int page_counter_ = 0x8000;
-    bool strict_;
+    bool strict_, pages_;
 };
 
 // Source concept: bool certainly_empty(x,y,z,size); uint8_t leaf_mask(x,y,z) for a 2^3 block.
@@ -169,24 +175,13 @@ struct DenseSource {
 };
 
 // ---- synthetic scene "shell-terrain"  ---------------------------
-inline uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ULL;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
-    return x ^ (x >> 31);
-}
-
-inline uint64_t lattice(uint64_t seed, int octave, int64_t i, int64_t j) {
-    return splitmix64(seed * 0x100000001B3ULL ^ splitmix64(((uint64_t)octave << 56) ^ ((uint64_t)i << 28) ^ (uint64_t)j));
-}
-
 // Integer bilinear value noise: octaves with cell 2^k, k = depth-2 .. 2,
 // amplitude dim / 2^(o+2) for the o-th octave, offset dim/4.
-void make_heightfield(uint32_t depth, uint64_t seed, std::vector<int32_t> &h) {
+void make_heightfield(uint32_t depth, uint64_t seed, std::vector<int32_t> &h, int octave_floor = 2) {
     const int64_t dim = 1LL << depth;
     h.assign((size_t)(dim * dim), (int32_t)(dim / 4));
     int o = 0;
-    for (int k = (int)depth - 2; k >= 2; k--, o++) {
+    for (int k = (int)depth - 2; k >= octave_floor; k--, o++) {
         const int64_t cell = 1LL << k;
         const int64_t amp = dim >> (o + 2);
         if (amp <= 0) break;
@@ -326,19 +321,40 @@ int vrc_octree_generate(const int8_t *grid, uint32_t dim, uint64_t buffer_size, 
     return *descriptors ? VRC_OK : VRC_ERR_OUT_OF_MEMORY;
 }
 
-int vrc_scene_shell_terrain(uint32_t depth, uint64_t seed, int32_t thickness, int strict_reference,
-                            uint64_t **descriptors, uint64_t *n_descriptors, uint64_t *root_index,
-                            int32_t *height) {
-    if (depth < 3 || depth > 16 || !descriptors || !n_descriptors || !root_index) return VRC_ERR_INVALID_ARGUMENT;
+int vrc_scene_shell_terrain_ex(uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor, uint32_t layout,
+                               uint64_t **descriptors, uint64_t *n_descriptors, uint64_t *root_index, int32_t *height) {
+    if (depth < 3 || depth > 16 || octave_floor < 0 || thickness < 0 || !descriptors || !n_descriptors || !root_index)
+        return VRC_ERR_INVALID_ARGUMENT;
     std::vector<int32_t> h;
-    make_heightfield(depth, seed, h);
+    make_heightfield(depth, seed, h, octave_floor);
     if (height) memcpy(height, h.data(), h.size() * sizeof(int32_t));
     ShellSource src;
     src.init(depth, h, thickness);
-    Emitter em(strict_reference != 0);
+    Emitter em((layout & VRC_LAYOUT_STRICT_REFERENCE) != 0, (layout & VRC_LAYOUT_NO_PAGE_HEADERS) == 0);
     Node root = build(em, src, 0, 0, 0, 1 << depth);
     em.finish(root.desc, 0, descriptors, n_descriptors, root_index);
     return *descriptors ? VRC_OK : VRC_ERR_OUT_OF_MEMORY;
+}
+
+int vrc_scene_shell_terrain(uint32_t depth, uint64_t seed, int32_t thickness, int strict_reference,
+                            uint64_t **descriptors, uint64_t *n_descriptors, uint64_t *root_index,
+                            int32_t *height) {
+    return vrc_scene_shell_terrain_ex(depth, seed, thickness, 2, strict_reference ? VRC_LAYOUT_STRICT_REFERENCE : 0u,
+                                      descriptors, n_descriptors, root_index, height);
+}
+
+int vrc_scene_shell_column(uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor, int64_t x, int64_t y,
+                           int32_t *lo, int32_t *hi) {
+    const int64_t dim = 1LL << depth;
+    if (depth < 3 || depth > 16 || octave_floor < 0 || x < 0 || y < 0 || x >= dim || y >= dim || !lo || !hi) return VRC_ERR_INVALID_ARGUMENT;
+    const int32_t h = vrc::shell_height(depth, seed, octave_floor, x, y);
+    const int32_t hxm = x > 0 ? vrc::shell_height(depth, seed, octave_floor, x - 1, y) : h;
+    const int32_t hxp = x + 1 < dim ? vrc::shell_height(depth, seed, octave_floor, x + 1, y) : h;
+    const int32_t hym = y > 0 ? vrc::shell_height(depth, seed, octave_floor, x, y - 1) : h;
+    const int32_t hyp = y + 1 < dim ? vrc::shell_height(depth, seed, octave_floor, x, y + 1) : h;
+    *hi = h;
+    *lo = vrc::shell_floor(h, hxm, hxp, hym, hyp, thickness);
+    return VRC_OK;
 }
 
 int vrc_scene_shell_terrain_dense(uint32_t depth, uint64_t seed, int32_t thickness, int8_t *grid) {

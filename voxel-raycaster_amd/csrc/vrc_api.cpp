@@ -3,7 +3,13 @@
 // Plays the role of src/CLCaster.cpp in the reference: owns the device
 // buffers (its named buffer_map, :855-944), the settings buffer (:1029-1109),
 // validation (:157-206) and the per-frame launch (:224-228, 946-987) -- with
-// HIP streams/events on one MI355X instead of an OpenCL queue + GL interop.
+// HIP streams/events on MI355X instead of an OpenCL queue + GL interop.
+//
+// A handle drives one GPU.  A GROUP handle (vrc_create_group) is rank 0 of a set of handles, one per GPU, that share
+// one host thread: every assign_* / setting call is replicated, the octree is uploaded once and fanned out
+// device-to-device, each rank owns only its row bands of the ray table / frame (vrc_set_row_slice), vrc_compute
+// launches all ranks and returns when all are done, and the read-back calls gather every rank's rows into the
+// caller's frame.  No collective anywhere.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -22,6 +28,11 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream);
 hipError_t launch_frame_setup(const RaycastParams &p, hipStream_t stream);
 hipError_t launch_reduce_counters(const unsigned long long *partials, int nblocks, unsigned long long *out,
                                   hipStream_t stream);
+hipError_t launch_fill_image(float *image, size_t n_pixels, hipStream_t stream);
+hipError_t launch_pack_rgba8(const float *image, uint8_t *out, size_t n_pixels, hipStream_t stream);
+int build_shell_terrain_device(hipStream_t stream, uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor,
+                               uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
+                               int32_t *probe_lohi, uint64_t **d_desc, vrc_build_info *out, std::string &error);
 }  // namespace vrc
 
 struct vrc_setting { std::string name, define; int64_t value; };
@@ -34,13 +45,17 @@ struct vrc_caster {
     // scene buffers (device)
     int8_t *d_map = nullptr; int32_t map_dim[3] = {0, 0, 0};
     uint64_t *d_desc = nullptr; uint64_t n_desc = 0; bool have_octree = false;
-    uint32_t *d_attach_lookup = nullptr; uint64_t *d_attach = nullptr;
-    float *d_viewport = nullptr; float *d_image = nullptr; int32_t *d_hits = nullptr;
+    bool owns_desc = true;                // false: a group rank on the same GPU as rank 0 shares rank 0's arrays
+    uint32_t *d_attach_lookup = nullptr; uint64_t *d_attach = nullptr; uint64_t n_attach = 0;
+    float *d_viewport = nullptr; float *d_image = nullptr; int32_t *d_hits = nullptr; uint8_t *d_rgba8 = nullptr;
     int32_t width = 0, height = 0;
+    bool sliced = false;                  // viewport / image / hits hold only this rank's rows
+    int32_t buffer_rows = 0;              // rows the three buffers hold
     uint8_t *d_atlas = nullptr; int32_t atlas_w = 0, atlas_h = 0, tile_w = 0, tile_h = 0;
     unsigned long long *d_partials = nullptr; int partial_blocks = 0;
     unsigned long long *d_counters = nullptr;
     int32_t *d_frame = nullptr;           // {bias[3], reads}
+    unsigned int *wd_flag = nullptr;      // host-mapped: raised by the kernel's round watchdog
 
     // live (retained) host pointers
     const float *cam_dir = nullptr, *cam_pos = nullptr;
@@ -57,6 +72,10 @@ struct vrc_caster {
     struct EvPair { hipEvent_t a, b; };
     std::vector<EvPair> pending, pool;
     uint64_t timed_launches = 0; double timed_ms = 0.0;
+
+    // group: this handle is rank 0, peers are ranks 1..n-1
+    std::vector<vrc_caster *> peers;
+    bool is_peer = false;
 };
 
 namespace {
@@ -79,9 +98,26 @@ int fail(vrc_caster *h, int code, const char *fmt, ...) {
                         "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// replicate a call on every other rank of a group; the first failure is reported through rank 0
+#define FOR_PEERS(h, expr)                                                                        \
+    do {                                                                                          \
+        for (size_t pi_ = 0; pi_ < (h)->peers.size(); pi_++) {                                    \
+            vrc_caster *q = (h)->peers[pi_];                                                      \
+            const int rc_ = (expr);                                                               \
+            if (rc_ != VRC_OK) return fail(h, rc_, "rank %zu: %s", pi_ + 1, q->error.c_str());    \
+        }                                                                                         \
+    } while (0)
+
 template <class T>
 void release(T *&p) {
     if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+void release_tree(vrc_caster *h) {
+    if (h->owns_desc) { release(h->d_desc); release(h->d_attach_lookup); release(h->d_attach); }
+    h->d_desc = nullptr; h->d_attach_lookup = nullptr; h->d_attach = nullptr;
+    h->owns_desc = true;
+    h->n_desc = 0; h->n_attach = 0; h->have_octree = false; h->validated = false;
 }
 
 int find_setting(const vrc_caster *h, const char *name) {
@@ -119,6 +155,107 @@ void drain_events(vrc_caster *h) {
     h->pending.clear();
 }
 
+// The rows a handle renders, as runs: image rows [y0, y0 + n) live at buffer rows [b0, b0 + n).
+struct RowRun { int32_t y0, n, b0; };
+std::vector<RowRun> row_runs(const vrc_caster *h, bool buffer_sliced) {
+    std::vector<RowRun> runs;
+    int32_t b0 = 0;
+    for (int32_t y = h->tile_rank * h->band_rows; y < h->height; y += h->tile_world * h->band_rows) {
+        const int32_t n = std::min(h->band_rows, h->height - y);
+        runs.push_back({y, n, buffer_sliced ? b0 : y});
+        b0 += n;
+    }
+    return runs;
+}
+int32_t local_row_count(const vrc_caster *h) {
+    int32_t rows = 0;
+    for (const RowRun &r : row_runs(h, true)) rows += r.n;
+    return rows;
+}
+
+// one row of the reference's ray table (CLCaster.cpp:233-275): base ray (-800, x, y) slewed by the literal 1.57 about
+// Y in double, then normalised in float (util.hpp:64-73)
+void reference_table_row(int32_t width, int32_t height, int32_t row, float *out) {
+    const double s157 = std::sin(1.57), c157 = std::cos(1.57);
+    const int y = row - height / 2;
+    for (int x = -width / 2; x < width / 2; x++) {
+        const float bx = -800.0f, by = (float)x, bz = (float)y;
+        const float rx = (float)((double)bz * s157 + (double)bx * c157);
+        const float ry = by;
+        const float rz = (float)((double)bz * c157 - (double)bx * s157);
+        const float len = std::sqrt(rx * rx + ry * ry + rz * rz);
+        float *t = out + 4 * (size_t)(x + width / 2);
+        t[0] = rx / len; t[1] = ry / len; t[2] = rz / len; t[3] = 0.0f;
+    }
+}
+
+// allocate the viewport buffers (all rows, or this rank's rows when sliced) and upload the ray table run by run;
+// table == nullptr: the reference's own table
+int install_viewport(vrc_caster *h, int32_t width, int32_t height, const float *table) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8);
+    h->width = width; h->height = height;
+    h->buffer_rows = h->sliced ? local_row_count(h) : height;
+    h->validated = false;
+    const size_t npix = (size_t)width * (size_t)std::max(h->buffer_rows, 1);
+    HIP_TRY(h, hipMalloc((void **)&h->d_viewport, 16 * npix));
+    HIP_TRY(h, hipMalloc((void **)&h->d_image, 16 * npix));
+    std::vector<RowRun> runs = h->sliced ? row_runs(h, true) : std::vector<RowRun>{{0, height, 0}};
+    std::vector<float> stage;
+    const int32_t chunk = 64;                                     // rows per host staging buffer
+    for (const RowRun &r : runs)
+        for (int32_t o = 0; o < r.n; o += chunk) {
+            const int32_t n = std::min(chunk, r.n - o);
+            const float *src = table ? table + 4 * (size_t)width * (size_t)(r.y0 + o) : nullptr;
+            if (!table) {
+                // the reference's loops run x, y over [-w/2, w/2) x [-h/2, h/2): with an odd size the last column / row
+                // of its (zero-initialised) table is never written (CLCaster.cpp:242-275)
+                stage.assign(4 * (size_t)width * n, 0.0f);
+                for (int32_t k = 0; k < n; k++)
+                    if (r.y0 + o + k < 2 * (height / 2))
+                        reference_table_row(width, height, r.y0 + o + k, stage.data() + 4 * (size_t)width * k);
+                src = stage.data();
+            }
+            HIP_TRY(h, hipMemcpy(h->d_viewport + 4 * (size_t)width * (size_t)(r.b0 + o), src, 16 * (size_t)width * n, hipMemcpyHostToDevice));
+        }
+    // the image starts as RGBA8 (255,255,255,100)  (CLCaster.cpp:280-286)
+    HIP_TRY(h, vrc::launch_fill_image(h->d_image, npix, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return VRC_OK;
+}
+
+int ensure_hits(vrc_caster *h) {
+    if (h->d_hits || !h->d_viewport) return VRC_OK;
+    const size_t npix = (size_t)h->width * (size_t)std::max(h->buffer_rows, 1);
+    HIP_TRY(h, hipMalloc((void **)&h->d_hits, 32 * npix));
+    HIP_TRY(h, hipMemsetAsync(h->d_hits, 0, 32 * npix, h->stream));
+    return VRC_OK;
+}
+
+// device rows -> the caller's full-frame buffer, `bpp` bytes per pixel
+int copy_rows_out(vrc_caster *h, const void *dev, size_t bpp, void *host) {
+    const size_t row = (size_t)h->width * bpp;
+    if (!h->sliced) {
+        HIP_TRY(h, hipMemcpyAsync(host, dev, row * (size_t)h->height, hipMemcpyDeviceToHost, h->stream));
+        return VRC_OK;
+    }
+    for (const RowRun &r : row_runs(h, true))
+        HIP_TRY(h, hipMemcpyAsync((char *)host + row * (size_t)r.y0, (const char *)dev + row * (size_t)r.b0, row * (size_t)r.n,
+                                  hipMemcpyDeviceToHost, h->stream));
+    return VRC_OK;
+}
+
+int sync_one(vrc_caster *h) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    drain_events(h);
+    if (h->wd_flag && *(volatile unsigned int *)h->wd_flag) {
+        *(volatile unsigned int *)h->wd_flag = 0;
+        return fail(h, VRC_ERR_DEVICE, "the kernel's round watchdog stopped a wavefront: the frame is invalid (setting watchdog_rounds)");
+    }
+    return VRC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -142,25 +279,64 @@ int vrc_create(int device_ordinal, vrc_caster **out) {
     if (hipSetDevice(device_ordinal) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&h->d_counters, sizeof(unsigned long long) * vrc::kCtrCount) != hipSuccess ||
-        hipMalloc((void **)&h->d_frame, sizeof(int32_t) * 4) != hipSuccess) {
+        hipMalloc((void **)&h->d_frame, sizeof(int32_t) * 4) != hipSuccess ||
+        hipHostMalloc((void **)&h->wd_flag, sizeof(unsigned int), hipHostMallocMapped) != hipSuccess) {
         delete h;
         return VRC_ERR_DEVICE;
     }
+    *h->wd_flag = 0;
     (void)hipMemset(h->d_counters, 0, sizeof(unsigned long long) * vrc::kCtrCount);
     (void)hipMemset(h->d_frame, 0, sizeof(int32_t) * 4);
     *out = h;
     return VRC_OK;
 }
 
+int vrc_create_group(const int32_t *device_ordinals, int32_t n, int32_t band_rows, vrc_caster **out) {
+    if (!out || !device_ordinals || n < 1 || band_rows < vrc::kTileH || band_rows % vrc::kTileH) return VRC_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    vrc_caster *root = nullptr;
+    int rc = vrc_create(device_ordinals[0], &root);
+    if (rc != VRC_OK) return rc;
+    root->tile_rank = 0; root->tile_world = n; root->band_rows = band_rows; root->sliced = n > 1;
+    for (int32_t r = 1; r < n; r++) {
+        vrc_caster *q = nullptr;
+        rc = vrc_create(device_ordinals[r], &q);
+        if (rc != VRC_OK) { vrc_destroy(root); return rc; }
+        q->tile_rank = r; q->tile_world = n; q->band_rows = band_rows; q->sliced = true; q->is_peer = true;
+        root->peers.push_back(q);
+        if (q->device != root->device) {                       // SVO fan-out goes device to device over xGMI
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, q->device, root->device) == hipSuccess && can) {
+                (void)hipSetDevice(q->device);
+                (void)hipDeviceEnablePeerAccess(root->device, 0);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    (void)hipSetDevice(root->device);
+    *out = root;
+    return VRC_OK;
+}
+
+int vrc_group_size(const vrc_caster *h, int32_t *n) {
+    if (!h || !n) return VRC_ERR_INVALID_ARGUMENT;
+    *n = (int32_t)h->peers.size() + 1;
+    return VRC_OK;
+}
+
 int vrc_destroy(vrc_caster *h) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
+    for (vrc_caster *q : h->peers) vrc_destroy(q);
+    h->peers.clear();
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drain_events(h);
     for (auto &p : h->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    release(h->d_map); release(h->d_desc); release(h->d_attach_lookup); release(h->d_attach);
-    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_atlas);
+    release_tree(h);
+    release(h->d_map);
+    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_atlas);
     release(h->d_partials); release(h->d_counters); release(h->d_frame);
+    if (h->wd_flag) (void)hipHostFree(h->wd_flag);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return VRC_OK;
@@ -177,6 +353,7 @@ int vrc_assign_map(vrc_caster *h, const int8_t *voxels, int32_t dx, int32_t dy, 
     HIP_TRY(h, hipMemcpy(h->d_map, voxels, bytes, hipMemcpyHostToDevice));
     h->map_dim[0] = dx; h->map_dim[1] = dy; h->map_dim[2] = dz;
     h->validated = false;
+    FOR_PEERS(h, vrc_assign_map(q, voxels, dx, dy, dz));
     return VRC_OK;
 }
 
@@ -186,43 +363,120 @@ int vrc_release_map(vrc_caster *h) {
     release(h->d_map);
     h->map_dim[0] = h->map_dim[1] = h->map_dim[2] = 0;
     h->validated = false;
+    FOR_PEERS(h, vrc_release_map(q));
     return VRC_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+// Give every other rank of the group rank 0's tree: shared when the rank sits on the same GPU, copied device to
+// device otherwise (hipMemcpyPeerAsync: xGMI, no host staging; SURVEY 8e "peer fan-out").
+int fan_out_tree(vrc_caster *h) {
+    for (size_t i = 0; i < h->peers.size(); i++) {
+        vrc_caster *q = h->peers[i];
+        release_tree(q);
+        if (q->device == h->device) {
+            q->d_desc = h->d_desc; q->d_attach_lookup = h->d_attach_lookup; q->d_attach = h->d_attach;
+            q->owns_desc = false;
+        } else {
+            HIP_TRY(h, hipSetDevice(q->device));
+            HIP_TRY(h, hipMalloc((void **)&q->d_desc, h->n_desc * sizeof(uint64_t)));
+            HIP_TRY(h, hipMemcpyPeerAsync(q->d_desc, q->device, h->d_desc, h->device, h->n_desc * sizeof(uint64_t), q->stream));
+            if (h->d_attach_lookup && h->d_attach) {
+                HIP_TRY(h, hipMalloc((void **)&q->d_attach_lookup, h->n_desc * sizeof(uint32_t)));
+                HIP_TRY(h, hipMalloc((void **)&q->d_attach, std::max<uint64_t>(h->n_attach, 1) * sizeof(uint64_t)));
+                HIP_TRY(h, hipMemcpyPeerAsync(q->d_attach_lookup, q->device, h->d_attach_lookup, h->device, h->n_desc * sizeof(uint32_t), q->stream));
+                HIP_TRY(h, hipMemcpyPeerAsync(q->d_attach, q->device, h->d_attach, h->device,
+                                              std::max<uint64_t>(h->n_attach, 1) * sizeof(uint64_t), q->stream));
+            }
+        }
+        q->n_desc = h->n_desc; q->n_attach = h->n_attach; q->have_octree = true; q->validated = false;
+        int rc = set_setting(q, "octree_root_index", "OCTREE_ROOT_INDEX", setting_or(h, "octree_root_index", 0));
+        if (rc != VRC_OK) return rc;
+    }
+    for (vrc_caster *q : h->peers)
+        if (q->device != h->device) { HIP_TRY(h, hipSetDevice(q->device)); HIP_TRY(h, hipStreamSynchronize(q->stream)); }
+    HIP_TRY(h, hipSetDevice(h->device));
+    return VRC_OK;
+}
+
+bool lookup_in_range(const uint32_t *lookup, size_t n, uint64_t n_attach) {
+    const uint64_t limit = std::max<uint64_t>(n_attach, 1);
+    for (size_t i = 0; i < n; i++)
+        if (lookup[i] >= limit) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
 
 int vrc_assign_octree(vrc_caster *h, const uint64_t *descriptors, uint64_t n, uint64_t root_index) {
     if (!h || !descriptors || n == 0 || root_index >= n) return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    release(h->d_desc);
-    h->have_octree = false;
+    for (vrc_caster *q : h->peers) release_tree(q);
+    release_tree(h);                                               // a new tree never inherits the old one's materials
     HIP_TRY(h, hipMalloc((void **)&h->d_desc, n * sizeof(uint64_t)));
     HIP_TRY(h, hipMemcpy(h->d_desc, descriptors, n * sizeof(uint64_t), hipMemcpyHostToDevice));
     h->n_desc = n;
     h->have_octree = true;
-    h->validated = false;
-    return set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)root_index);   // CLCaster.cpp:113
+    int rc = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)root_index);   // CLCaster.cpp:113
+    if (rc != VRC_OK) return rc;
+    return fan_out_tree(h);
 }
 
 int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_t n_lookup,
                                   const uint64_t *attachments, uint64_t n_attachments) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
+    if (!h->have_octree) return fail(h, VRC_ERR_NOT_READY, "assign_octree_attachments: assign the octree first");
     HIP_TRY(h, hipSetDevice(h->device));
+    for (vrc_caster *q : h->peers)
+        if (!q->owns_desc) { q->d_attach_lookup = nullptr; q->d_attach = nullptr; q->n_attach = 0; }
     release(h->d_attach_lookup); release(h->d_attach);
-    if (lookup && n_lookup && n_lookup != h->n_desc)
-        return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_attachments: lookup must have one entry per descriptor (assign the octree first)");
-    if (lookup && n_lookup) {
+    h->n_attach = 0; h->validated = false;
+    if (lookup && n_lookup && attachments && n_attachments) {
+        if (n_lookup != h->n_desc)
+            return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_attachments: lookup must have one entry per descriptor");
+        if (!lookup_in_range(lookup, (size_t)n_lookup, n_attachments))
+            return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_attachments: a lookup entry points past the attachment buffer");
         HIP_TRY(h, hipMalloc((void **)&h->d_attach_lookup, n_lookup * sizeof(uint32_t)));
         HIP_TRY(h, hipMemcpy(h->d_attach_lookup, lookup, n_lookup * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
-    if (attachments && n_attachments) {
         HIP_TRY(h, hipMalloc((void **)&h->d_attach, n_attachments * sizeof(uint64_t)));
         HIP_TRY(h, hipMemcpy(h->d_attach, attachments, n_attachments * sizeof(uint64_t), hipMemcpyHostToDevice));
+        h->n_attach = n_attachments;
     }
+    if (h->peers.empty()) return VRC_OK;
+    // ranks on other GPUs own their copy of the descriptors: only the attachment buffers change
+    for (vrc_caster *q : h->peers) {
+        if (q->device == h->device) {
+            q->d_attach_lookup = h->d_attach_lookup; q->d_attach = h->d_attach; q->n_attach = h->n_attach;
+        } else {
+            HIP_TRY(h, hipSetDevice(q->device));
+            release(q->d_attach_lookup); release(q->d_attach);
+            q->n_attach = 0;
+            if (h->d_attach_lookup && h->d_attach) {
+                HIP_TRY(h, hipMalloc((void **)&q->d_attach_lookup, h->n_desc * sizeof(uint32_t)));
+                HIP_TRY(h, hipMalloc((void **)&q->d_attach, h->n_attach * sizeof(uint64_t)));
+                HIP_TRY(h, hipMemcpyPeer(q->d_attach_lookup, q->device, h->d_attach_lookup, h->device, h->n_desc * sizeof(uint32_t)));
+                HIP_TRY(h, hipMemcpyPeer(q->d_attach, q->device, h->d_attach, h->device, h->n_attach * sizeof(uint64_t)));
+                q->n_attach = h->n_attach;
+            }
+        }
+        q->validated = false;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
     return VRC_OK;
 }
 
+}  // extern "C"
+
 namespace {
-// file -> device through two pinned staging buffers: the read of chunk k+1 overlaps the copy of chunk k
-int stream_to_device(vrc_caster *h, FILE *f, void *dst, size_t bytes, void *stage[2], size_t chunk) {
+// file -> device through two pinned staging buffers: the read of chunk k+1 overlaps the copy of chunk k.
+// check (optional) looks at every staged chunk before it is sent.
+int stream_to_device(vrc_caster *h, FILE *f, void *dst, size_t bytes, void *stage[2], size_t chunk,
+                     bool (*check)(const void *, size_t, uint64_t), uint64_t check_arg) {
     hipEvent_t done[2] = {nullptr, nullptr};
     for (int i = 0; i < 2; i++) HIP_TRY(h, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
     int rc = VRC_OK;
@@ -231,6 +485,7 @@ int stream_to_device(vrc_caster *h, FILE *f, void *dst, size_t bytes, void *stag
         const size_t n = std::min(chunk, bytes - off);
         if (hipEventSynchronize(done[k]) != hipSuccess) { rc = fail(h, VRC_ERR_DEVICE, "assign_octree_file: event wait failed"); break; }
         if (fread(stage[k], 1, n, f) != n) { rc = fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_file: file is truncated"); break; }
+        if (check && !check(stage[k], n, check_arg)) { rc = fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_file: a lookup entry points past the attachment buffer"); break; }
         if (hipMemcpyAsync((char *)dst + off, stage[k], n, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipEventRecord(done[k], h->stream) != hipSuccess) { rc = fail(h, VRC_ERR_DEVICE, "assign_octree_file: upload failed"); break; }
         off += n;
@@ -239,7 +494,12 @@ int stream_to_device(vrc_caster *h, FILE *f, void *dst, size_t bytes, void *stag
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(done[i]);
     return rc;
 }
+bool check_lookup_chunk(const void *p, size_t bytes, uint64_t n_attach) {
+    return lookup_in_range((const uint32_t *)p, bytes / sizeof(uint32_t), n_attach);
+}
 }  // namespace
+
+extern "C" {
 
 int vrc_assign_octree_file(vrc_caster *h, const char *path, uint32_t *dim) {
     if (!h || !path || !dim) return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_file: null argument");
@@ -253,90 +513,108 @@ int vrc_assign_octree_file(vrc_caster *h, const char *path, uint32_t *dim) {
                         fread(&flags, 4, 1, f) == 1 && fread(&root, 8, 1, f) == 1 && fread(&n, 8, 1, f) == 1 &&
                         fread(&na, 8, 1, f) == 1 && n > 0 && root < n && *dim >= 2 && (*dim & (*dim - 1)) == 0;
     if (!header) { fclose(f); return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_file: '%s' is not a VRCSVO01 file", path); }
-    release(h->d_desc); release(h->d_attach_lookup); release(h->d_attach);
-    h->have_octree = false; h->n_desc = 0; h->validated = false;
-    const size_t chunk = (size_t)64 << 20;
+    for (vrc_caster *q : h->peers) release_tree(q);
+    release_tree(h);
+    const size_t chunk = (size_t)setting_or(h, "upload_chunk_bytes", 64 << 20);
     void *stage[2] = {nullptr, nullptr};
     int rc = VRC_OK;
-    if (hipHostMalloc(&stage[0], chunk, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&stage[1], chunk, hipHostMallocDefault) != hipSuccess)
+    if (chunk < 4096 || hipHostMalloc(&stage[0], chunk, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&stage[1], chunk, hipHostMallocDefault) != hipSuccess)
         rc = fail(h, VRC_ERR_OUT_OF_MEMORY, "assign_octree_file: no pinned staging memory");
     if (rc == VRC_OK && hipMalloc((void **)&h->d_desc, n * sizeof(uint64_t)) != hipSuccess)
         rc = fail(h, VRC_ERR_OUT_OF_MEMORY, "assign_octree_file: %llu descriptors do not fit in device memory", (unsigned long long)n);
-    if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_desc, n * sizeof(uint64_t), stage, chunk);
+    if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_desc, n * sizeof(uint64_t), stage, chunk, nullptr, 0);
     if (rc == VRC_OK && (flags & 1u)) {
         if (hipMalloc((void **)&h->d_attach_lookup, n * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc((void **)&h->d_attach, (na ? na : 1) * sizeof(uint64_t)) != hipSuccess)
             rc = fail(h, VRC_ERR_OUT_OF_MEMORY, "assign_octree_file: attachment buffers do not fit in device memory");
-        if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_attach_lookup, n * sizeof(uint32_t), stage, chunk);
-        if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_attach, na * sizeof(uint64_t), stage, chunk);
+        if (rc == VRC_OK && na == 0 && hipMemset(h->d_attach, 0x05, sizeof(uint64_t)) != hipSuccess)
+            rc = fail(h, VRC_ERR_DEVICE, "assign_octree_file: memset failed");
+        if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_attach_lookup, n * sizeof(uint32_t), stage, chunk, check_lookup_chunk, na);
+        if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_attach, na * sizeof(uint64_t), stage, chunk, nullptr, 0);
     }
     fclose(f);
     for (int i = 0; i < 2; i++) if (stage[i]) (void)hipHostFree(stage[i]);
-    if (rc != VRC_OK) { release(h->d_desc); release(h->d_attach_lookup); release(h->d_attach); return rc; }
-    h->n_desc = n;
+    if (rc != VRC_OK) { release_tree(h); return rc; }
+    h->n_desc = n; h->n_attach = (flags & 1u) ? std::max<uint64_t>(na, 1) : 0;
     h->have_octree = true;
-    return set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)root);   // CLCaster.cpp:113
+    rc = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)root);   // CLCaster.cpp:113
+    if (rc != VRC_OK) return rc;
+    return fan_out_tree(h);
+}
+
+int vrc_build_shell_terrain(vrc_caster *h, uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor,
+                            uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
+                            int32_t *probe_lohi, vrc_build_info *info) {
+    if (!h || depth < 3 || depth > 16 || thickness < 0 || octave_floor < 0)
+        return fail(h, VRC_ERR_INVALID_ARGUMENT, "build_shell_terrain: need 3 <= depth <= 16, thickness >= 0, octave_floor >= 0");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool count_only = (flags & VRC_BUILD_COUNT_ONLY) != 0;
+    if (!count_only) {
+        for (vrc_caster *q : h->peers) release_tree(q);
+        release_tree(h);
+    }
+    uint64_t *d = nullptr;
+    vrc_build_info bi;
+    std::string err;
+    const int rc = vrc::build_shell_terrain_device(h->stream, depth, seed, thickness, octave_floor, flags, validate_samples, probe_xy,
+                                                   n_probe, probe_lohi, &d, &bi, err);
+    if (info) *info = bi;
+    if (rc != VRC_OK) return fail(h, rc, "build_shell_terrain: %s", err.c_str());
+    if (count_only) return VRC_OK;
+    h->d_desc = d; h->n_desc = bi.n_descriptors; h->have_octree = true;
+    const int rs = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)bi.root_index);
+    if (rs != VRC_OK) return rs;
+    return fan_out_tree(h);
+}
+
+int vrc_read_descriptors(vrc_caster *h, uint64_t first, uint64_t count, uint64_t *out) {
+    if (!h || !out) return VRC_ERR_INVALID_ARGUMENT;
+    if (!h->have_octree) return fail(h, VRC_ERR_NOT_READY, "read_descriptors: no octree assigned");
+    if (first > h->n_desc || count > h->n_desc - first) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_descriptors: range past the array");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(out, h->d_desc + first, count * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return VRC_OK;
+}
+
+int vrc_octree_size(vrc_caster *h, uint64_t *n_descriptors, uint64_t *root_index) {
+    if (!h) return VRC_ERR_INVALID_ARGUMENT;
+    if (!h->have_octree) return fail(h, VRC_ERR_NOT_READY, "octree_size: no octree assigned");
+    if (n_descriptors) *n_descriptors = h->n_desc;
+    if (root_index) *root_index = (uint64_t)setting_or(h, "octree_root_index", 0);
+    return VRC_OK;
 }
 
 int vrc_release_octree(vrc_caster *h) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_desc) return fail(h, VRC_ERR_NOT_FOUND, "release_octree: no octree assigned");
-    release(h->d_desc); release(h->d_attach_lookup); release(h->d_attach);
-    h->n_desc = 0; h->have_octree = false; h->validated = false;
-    return VRC_OK;
-}
-
-static int install_viewport(vrc_caster *h, int32_t width, int32_t height, std::vector<float> &table) {
-    HIP_TRY(h, hipSetDevice(h->device));
-    release(h->d_viewport); release(h->d_image); release(h->d_hits);
-    const size_t npix = (size_t)width * height;
-    HIP_TRY(h, hipMalloc((void **)&h->d_viewport, 16 * npix));
-    HIP_TRY(h, hipMemcpy(h->d_viewport, table.data(), 16 * npix, hipMemcpyHostToDevice));
-    // image starts as RGBA8 (255,255,255,100)  (CLCaster.cpp:280-286)
-    for (size_t i = 0; i < npix; i++) {
-        table[4 * i + 0] = 1.0f; table[4 * i + 1] = 1.0f; table[4 * i + 2] = 1.0f; table[4 * i + 3] = 100.0f / 255.0f;
-    }
-    HIP_TRY(h, hipMalloc((void **)&h->d_image, 16 * npix));
-    HIP_TRY(h, hipMemcpy(h->d_image, table.data(), 16 * npix, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMalloc((void **)&h->d_hits, 32 * npix));
-    HIP_TRY(h, hipMemset(h->d_hits, 0, 32 * npix));
-    h->width = width; h->height = height;
-    h->validated = false;
+    for (vrc_caster *q : h->peers) release_tree(q);               // ranks sharing rank 0's arrays must let go first
+    release_tree(h);
     return VRC_OK;
 }
 
 int vrc_create_viewport(vrc_caster *h, int32_t width, int32_t height, float v_fov, float h_fov) {
     (void)v_fov; (void)h_fov;              // ignored by the reference too (CLCaster.cpp:233-275)
     if (!h || width <= 0 || height <= 0) return fail(h, VRC_ERR_INVALID_ARGUMENT, "create_viewport: bad size");
-    const size_t npix = (size_t)width * height;
-    std::vector<float> table(4 * npix, 0.0f);
-    // base ray (-800, x, y) slewed by the literal 1.57 about Y in double, then
-    // normalised in float (util.hpp:64-73)
-    const double s157 = std::sin(1.57), c157 = std::cos(1.57);
-    for (int y = -height / 2; y < height / 2; y++)
-        for (int x = -width / 2; x < width / 2; x++) {
-            const float bx = -800.0f, by = (float)x, bz = (float)y;
-            const float rx = (float)((double)bz * s157 + (double)bx * c157);
-            const float ry = by;
-            const float rz = (float)((double)bz * c157 - (double)bx * s157);
-            const float len = std::sqrt(rx * rx + ry * ry + rz * rz);
-            float *t = &table[4 * ((size_t)(x + width / 2) + (size_t)width * (size_t)(y + height / 2))];
-            t[0] = rx / len; t[1] = ry / len; t[2] = rz / len; t[3] = 0.0f;
-        }
-    return install_viewport(h, width, height, table);
+    const int rc = install_viewport(h, width, height, nullptr);
+    if (rc != VRC_OK) return rc;
+    FOR_PEERS(h, vrc_create_viewport(q, width, height, v_fov, h_fov));
+    return VRC_OK;
 }
 
 int vrc_create_viewport_table(vrc_caster *h, int32_t width, int32_t height, const float *table) {
     if (!h || !table || width <= 0 || height <= 0) return fail(h, VRC_ERR_INVALID_ARGUMENT, "create_viewport_table: bad argument");
-    std::vector<float> copy(table, table + (size_t)4 * width * height);
-    return install_viewport(h, width, height, copy);
+    const int rc = install_viewport(h, width, height, table);
+    if (rc != VRC_OK) return rc;
+    FOR_PEERS(h, vrc_create_viewport_table(q, width, height, table));
+    return VRC_OK;
 }
 
 int vrc_release_viewport(vrc_caster *h) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_viewport) return fail(h, VRC_ERR_NOT_FOUND, "release_viewport: no viewport");
-    release(h->d_viewport); release(h->d_image); release(h->d_hits);
-    h->width = h->height = 0; h->validated = false;
+    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8);
+    h->width = h->height = h->buffer_rows = 0; h->validated = false;
+    FOR_PEERS(h, vrc_release_viewport(q));
     return VRC_OK;
 }
 
@@ -350,6 +628,7 @@ int vrc_create_texture_atlas(vrc_caster *h, const uint8_t *rgba8, int32_t width,
     HIP_TRY(h, hipMemcpy(h->d_atlas, rgba8, (size_t)4 * width * height, hipMemcpyHostToDevice));
     h->atlas_w = width; h->atlas_h = height; h->tile_w = tile_w; h->tile_h = tile_h;
     h->validated = false;
+    FOR_PEERS(h, vrc_create_texture_atlas(q, rgba8, width, height, tile_w, tile_h));
     return VRC_OK;
 }
 
@@ -357,12 +636,14 @@ int vrc_assign_camera(vrc_caster *h, const float *direction2, const float *posit
     if (!h || !direction2 || !position3) return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_camera: null pointer");
     h->cam_dir = direction2; h->cam_pos = position3;
     h->validated = false;
+    FOR_PEERS(h, vrc_assign_camera(q, direction2, position3));
     return VRC_OK;
 }
 
 int vrc_release_camera(vrc_caster *h) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     h->cam_dir = h->cam_pos = nullptr; h->validated = false;
+    FOR_PEERS(h, vrc_release_camera(q));
     return VRC_OK;
 }
 
@@ -370,12 +651,16 @@ int vrc_assign_lights(vrc_caster *h, const float *packed, const int32_t *light_c
     if (!h || !packed || !light_count) return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_lights: null pointer");
     h->lights = packed; h->light_count = light_count;
     h->validated = false;
+    FOR_PEERS(h, vrc_assign_lights(q, packed, light_count));
     return VRC_OK;
 }
 
 int vrc_setting_add(vrc_caster *h, const char *name, const char *define, int64_t value) {
     if (!h || !name) return VRC_ERR_INVALID_ARGUMENT;
-    return set_setting(h, name, define, value);
+    const int rc = set_setting(h, name, define, value);
+    if (rc != VRC_OK) return rc;
+    FOR_PEERS(h, vrc_setting_add(q, name, define, value));
+    return VRC_OK;
 }
 
 int vrc_setting_set(vrc_caster *h, const char *name, int64_t value) {
@@ -383,6 +668,7 @@ int vrc_setting_set(vrc_caster *h, const char *name, int64_t value) {
     int i = find_setting(h, name);
     if (i < 0) return fail(h, VRC_ERR_NOT_FOUND, "overwrite_setting: no setting named '%s'", name);   // CLCaster.cpp:1096-1100
     h->settings[i].value = value;
+    FOR_PEERS(h, vrc_setting_set(q, name, value));
     return VRC_OK;
 }
 
@@ -397,7 +683,18 @@ int vrc_setting_get(vrc_caster *h, const char *name, int64_t *value) {
 int vrc_set_row_tiling(vrc_caster *h, int32_t rank, int32_t world, int32_t band_rows) {
     if (!h || world < 1 || rank < 0 || rank >= world || band_rows < vrc::kTileH || band_rows % vrc::kTileH)
         return fail(h, VRC_ERR_INVALID_ARGUMENT, "set_row_tiling: need 0 <= rank < world and band_rows a multiple of 8");
+    if (!h->peers.empty() || h->is_peer) return fail(h, VRC_ERR_INVALID_ARGUMENT, "set_row_tiling: the ranks of a group are tiled by vrc_create_group");
+    if (h->sliced) return fail(h, VRC_ERR_INVALID_ARGUMENT, "set_row_tiling: this handle holds a row slice (vrc_set_row_slice); release the viewport first");
     h->tile_rank = rank; h->tile_world = world; h->band_rows = band_rows;
+    return VRC_OK;
+}
+
+int vrc_set_row_slice(vrc_caster *h, int32_t rank, int32_t world, int32_t band_rows) {
+    if (!h || world < 1 || rank < 0 || rank >= world || band_rows < vrc::kTileH || band_rows % vrc::kTileH)
+        return fail(h, VRC_ERR_INVALID_ARGUMENT, "set_row_slice: need 0 <= rank < world and band_rows a multiple of 8");
+    if (!h->peers.empty() || h->is_peer) return fail(h, VRC_ERR_INVALID_ARGUMENT, "set_row_slice: the ranks of a group are sliced by vrc_create_group");
+    if (h->d_viewport) return fail(h, VRC_ERR_NOT_READY, "set_row_slice: call it before create_viewport (the buffers are sized by it)");
+    h->tile_rank = rank; h->tile_world = world; h->band_rows = band_rows; h->sliced = world > 1;
     return VRC_OK;
 }
 
@@ -423,31 +720,51 @@ int vrc_validate(vrc_caster *h) {
     }
     if (h->atlas_w / h->tile_w <= 0 || h->atlas_h / h->tile_h <= 0) return fail(h, VRC_ERR_INVALID_ARGUMENT, "validate: tile larger than atlas");
     h->validated = true;
+    FOR_PEERS(h, vrc_validate(q));
     return VRC_OK;
 }
 
-int vrc_compute_async(vrc_caster *h) {
-    if (!h) return VRC_ERR_INVALID_ARGUMENT;
+}  // extern "C"
+
+namespace {
+
+int compute_async_one(vrc_caster *h) {
     if (!h->validated) return fail(h, VRC_ERR_NOT_READY, "compute: validate() has not succeeded");
     HIP_TRY(h, hipSetDevice(h->device));
 
+    // settings stay live after validate() (CLCaster::overwrite_setting needs no recompile, CLCaster.cpp:1087-1109), so
+    // the structural ones are checked again here: a bad value is an error return, never a device fault
     vrc::RaycastParams p;
     memset(&p, 0, sizeof(p));
     const bool svo = setting_or(h, "using_octree", 0) == 0;
     const int64_t dim = setting_or(h, "octree_dimensions", 0);
     p.svo = svo ? 1 : 0;
     p.log2_dim = log2_exact(dim);
+    if (p.log2_dim < 1 || p.log2_dim > vrc::kMaxLevels)
+        return fail(h, VRC_ERR_INVALID_ARGUMENT, "compute: octree_dimensions must be a power of two in [2, 2^%d]", vrc::kMaxLevels);
+    const int64_t root = setting_or(h, "octree_root_index", 0);
+    if (!h->d_desc || root < 0 || (uint64_t)root >= h->n_desc) return fail(h, VRC_ERR_INVALID_ARGUMENT, "compute: octree_root_index out of range");
+    if (!svo && !h->d_map) return fail(h, VRC_ERR_NOT_READY, "compute: dense map not assigned (using_octree != 0 selects the array branch)");
+    if (!h->d_viewport || !h->d_image || !h->d_atlas) return fail(h, VRC_ERR_NOT_READY, "compute: viewport or atlas released since validate()");
+    p.stepping_mode = (int32_t)setting_or(h, "stepping_mode", 0);
+    if (p.stepping_mode < 0 || p.stepping_mode > 1 || (p.stepping_mode == 1 && !svo))
+        return fail(h, VRC_ERR_INVALID_ARGUMENT, "compute: stepping_mode must be 0 (exact) or 1 (node-exit jumps, SVO branch only)");
     p.map = h->d_map;
     if (svo) { p.map_dim[0] = p.map_dim[1] = p.map_dim[2] = (int32_t)dim; }
     else { p.map_dim[0] = h->map_dim[0]; p.map_dim[1] = h->map_dim[1]; p.map_dim[2] = h->map_dim[2]; }
     p.width = h->width; p.height = h->height;
-    p.viewport = h->d_viewport; p.image = h->d_image; p.hits = h->d_hits;
+    if (setting_or(h, "hit_records", 1) != 0) {
+        const int rc = ensure_hits(h);
+        if (rc != VRC_OK) return rc;
+        p.hits = h->d_hits;
+    }
+    p.viewport = h->d_viewport; p.image = h->d_image;
     p.atlas = h->d_atlas; p.atlas_w = h->atlas_w; p.atlas_h = h->atlas_h;
     p.tiles_x = h->atlas_w / h->tile_w; p.tiles_y = h->atlas_h / h->tile_h;
     p.descriptors = h->d_desc;
     p.attach_lookup = (h->d_attach_lookup && h->d_attach) ? h->d_attach_lookup : nullptr;
     p.attachments = p.attach_lookup ? h->d_attach : nullptr;
-    p.root_index = (uint64_t)setting_or(h, "octree_root_index", 0);
+    p.root_index = (uint64_t)root;
     // live buffers are re-read every frame (CL_MEM_USE_HOST_PTR semantics)
     for (int a = 0; a < 3; a++) p.cam_pos[a] = h->cam_pos[a];
     p.trig[0] = sinf(h->cam_dir[0]); p.trig[1] = cosf(h->cam_dir[0]);
@@ -456,9 +773,16 @@ int vrc_compute_async(vrc_caster *h) {
     // "light_count" (default 1) switches on the multi-light extension for the first n packed lights
     p.light_count = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(setting_or(h, "light_count", 1), *h->light_count),
                                                                     vrc::kMaxLights));
+    double light_reach = 0.0;              // steps a shadow ray may take beyond max_distance: |voxel - light| (:667)
     for (int l = 0; l < p.light_count; l++) {
         for (int k = 0; k < 7; k++) p.lights[l][k] = h->lights[10 * l + k];
         p.lights[l][7] = 0.0f;
+        double far2 = 0.0;
+        for (int a = 0; a < 3; a++) {
+            const double lo = std::fabs((double)p.lights[l][4 + a]), hi = std::fabs((double)p.lights[l][4 + a] - (double)p.map_dim[a]);
+            far2 += std::max(lo, hi) * std::max(lo, hi);
+        }
+        light_reach += std::sqrt(far2) + 2.0;
     }
     p.max_distance = (int32_t)setting_or(h, "max_distance", 20);
     p.shadow_rays = (int32_t)setting_or(h, "shadow_rays", 1);
@@ -469,8 +793,12 @@ int vrc_compute_async(vrc_caster *h) {
     p.widen_nodes = (int32_t)setting_or(h, "widen_nodes", 1);
     p.octree_bias = (int32_t)setting_or(h, "octree_bias", 1);
     p.arith_mask = (int32_t)setting_or(h, "arith_mask", 1);
+    // every round advances at least one lane by a step, an event or a hit block: 64 lanes x (the longest legal ray:
+    // max_distance primary steps + per light the distance to the farthest map corner) with a 2x margin
+    const double legal_steps = (double)std::max(p.max_distance, 0) + light_reach + 64.0;
     p.watchdog_rounds = (int32_t)std::min<int64_t>(INT32_MAX, std::max<int64_t>(1, setting_or(h, "watchdog_rounds",
-                                    64LL * ((int64_t)p.max_distance + 64) * (p.light_count + 1))));
+                                    (int64_t)std::min(2.0e9, 128.0 * legal_steps))));
+    p.watchdog_flag = h->wd_flag;
     p.safe_run = (int32_t)setting_or(h, "safe_run", 1);
     p.single_step = (int32_t)setting_or(h, "single_step", 1);
     p.safe_steps = (int32_t)std::min<int64_t>(256, std::max<int64_t>(2, setting_or(h, "safe_steps", vrc::kDefaultSafeSteps)));
@@ -482,6 +810,7 @@ int vrc_compute_async(vrc_caster *h) {
     const int tile_rows = (h->height + vrc::kTileH - 1) / vrc::kTileH;
     p.band_tiles = h->band_rows / vrc::kTileH;
     p.tile_rank = h->tile_rank; p.tile_world = h->tile_world;
+    p.row_sliced = h->sliced ? 1 : 0;
     const int bands = (tile_rows + p.band_tiles - 1) / p.band_tiles;
     int local_rows = 0;
     for (int b = h->tile_rank; b < bands; b += h->tile_world) {
@@ -493,6 +822,7 @@ int vrc_compute_async(vrc_caster *h) {
     const int nblocks = p.blocks_x * p.local_tile_rows;
     if (nblocks > h->partial_blocks) {
         release(h->d_partials);
+        h->partial_blocks = 0;
         HIP_TRY(h, hipMalloc((void **)&h->d_partials, sizeof(unsigned long long) * vrc::kCtrCount * (size_t)nblocks));
         h->partial_blocks = nblocks;
     }
@@ -512,77 +842,149 @@ int vrc_compute_async(vrc_caster *h) {
     return VRC_OK;
 }
 
+// what read_image / read_hits / read_image_rgba8 have in common: every rank copies its rows into the caller's frame
+// (asynchronously, each on its own stream), then all ranks are waited for
+template <class Enqueue>
+int gather_rows(vrc_caster *h, Enqueue enqueue) {
+    int rc = enqueue(h);
+    if (rc != VRC_OK) return rc;
+    for (size_t i = 0; i < h->peers.size(); i++) {
+        rc = enqueue(h->peers[i]);
+        if (rc != VRC_OK) return fail(h, rc, "rank %zu: %s", i + 1, h->peers[i]->error.c_str());
+    }
+    rc = sync_one(h);
+    if (rc != VRC_OK) return rc;
+    FOR_PEERS(h, sync_one(q));
+    HIP_TRY(h, hipSetDevice(h->device));
+    return VRC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vrc_compute_async(vrc_caster *h) {
+    if (!h) return VRC_ERR_INVALID_ARGUMENT;
+    const int rc = compute_async_one(h);
+    if (rc != VRC_OK) return rc;
+    FOR_PEERS(h, compute_async_one(q));
+    if (!h->peers.empty()) HIP_TRY(h, hipSetDevice(h->device));
+    return VRC_OK;
+}
+
 int vrc_sync(vrc_caster *h) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    drain_events(h);
-    return VRC_OK;
+    int rc = sync_one(h);
+    for (size_t i = 0; i < h->peers.size(); i++) {                 // always wait for every rank, then report the first failure
+        const int rq = sync_one(h->peers[i]);
+        if (rq != VRC_OK && rc == VRC_OK) rc = fail(h, rq, "rank %zu: %s", i + 1, h->peers[i]->error.c_str());
+    }
+    if (!h->peers.empty()) (void)hipSetDevice(h->device);
+    return rc;
 }
 
 int vrc_compute(vrc_caster *h) {
     int rc = vrc_compute_async(h);
     if (rc != VRC_OK) return rc;
-    return vrc_sync(h);                    // clFinish (CLCaster.cpp:970)
+    return vrc_sync(h);                    // clFinish (CLCaster.cpp:970): the frame is complete on every rank
 }
 
 int vrc_read_image_f32(vrc_caster *h, float *rgba, size_t n_floats) {
     if (!h || !rgba) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_image) return fail(h, VRC_ERR_NOT_READY, "read_image: no viewport");
-    const size_t need = (size_t)4 * h->width * h->height;
-    if (n_floats < need) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_image_f32: buffer too small");
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(rgba, h->d_image, need * sizeof(float), hipMemcpyDeviceToHost));
-    return VRC_OK;
+    if (n_floats < (size_t)4 * h->width * h->height) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_image_f32: buffer too small");
+    return gather_rows(h, [rgba](vrc_caster *q) -> int {
+        HIP_TRY(q, hipSetDevice(q->device));
+        return copy_rows_out(q, q->d_image, 16, rgba);
+    });
 }
 
+// CLCaster::draw's source (CLCaster.cpp:278-296,330-332) is an RGBA8 texture the kernel's write_imagef quantises into:
+// saturate, scale by 255, round to nearest even.  Packed on the device, 4 bytes per pixel cross PCIe.
 int vrc_read_image_rgba8(vrc_caster *h, uint8_t *rgba, size_t n_bytes) {
     if (!h || !rgba) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_image) return fail(h, VRC_ERR_NOT_READY, "read_image: no viewport");
-    const size_t need = (size_t)4 * h->width * h->height;
-    if (n_bytes < need) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_image_rgba8: buffer too small");
-    std::vector<float> tmp(need);
-    int rc = vrc_read_image_f32(h, tmp.data(), need);
-    if (rc != VRC_OK) return rc;
-    // write_imagef to a UNORM_INT8 target: saturate, scale, round to nearest even
-    for (size_t i = 0; i < need; i++) {
-        float v = tmp[i];
-        if (!(v > 0.0f)) v = 0.0f;
-        if (v > 1.0f) v = 1.0f;
-        rgba[i] = (uint8_t)lrintf(v * 255.0f);
-    }
-    return VRC_OK;
+    if (n_bytes < (size_t)4 * h->width * h->height) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_image_rgba8: buffer too small");
+    return gather_rows(h, [rgba](vrc_caster *q) -> int {
+        HIP_TRY(q, hipSetDevice(q->device));
+        const size_t npix = (size_t)q->width * (size_t)std::max(q->buffer_rows, 1);
+        if (!q->d_rgba8) HIP_TRY(q, hipMalloc((void **)&q->d_rgba8, 4 * npix));
+        HIP_TRY(q, vrc::launch_pack_rgba8(q->d_image, q->d_rgba8, npix, q->stream));
+        return copy_rows_out(q, q->d_rgba8, 4, rgba);
+    });
 }
 
 int vrc_read_hits(vrc_caster *h, int32_t *hits, size_t n_int32) {
     if (!h || !hits) return VRC_ERR_INVALID_ARGUMENT;
-    if (!h->d_hits) return fail(h, VRC_ERR_NOT_READY, "read_hits: no viewport");
-    const size_t need = (size_t)8 * h->width * h->height;
-    if (n_int32 < need) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_hits: buffer too small");
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(hits, h->d_hits, need * sizeof(int32_t), hipMemcpyDeviceToHost));
-    return VRC_OK;
+    if (!h->d_viewport) return fail(h, VRC_ERR_NOT_READY, "read_hits: no viewport");
+    if (!h->d_hits) return fail(h, VRC_ERR_NOT_READY, "read_hits: no hit records (setting hit_records is 0, or no frame computed yet)");
+    if (n_int32 < (size_t)8 * h->width * h->height) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_hits: buffer too small");
+    return gather_rows(h, [hits](vrc_caster *q) -> int {
+        HIP_TRY(q, hipSetDevice(q->device));
+        if (!q->d_hits) return fail(q, VRC_ERR_NOT_READY, "read_hits: no hit records");
+        return copy_rows_out(q, q->d_hits, 32, hits);
+    });
 }
 
 int vrc_device_image(vrc_caster *h, void **dev_ptr, size_t *n_bytes) {
     if (!h || !dev_ptr) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_image) return fail(h, VRC_ERR_NOT_READY, "device_image: no viewport");
     *dev_ptr = h->d_image;
-    if (n_bytes) *n_bytes = (size_t)16 * h->width * h->height;
+    if (n_bytes) *n_bytes = (size_t)16 * h->width * (size_t)h->buffer_rows;
     return VRC_OK;
 }
 
-int vrc_get_counters(vrc_caster *h, vrc_counters *out) {
-    if (!h || !out) return VRC_ERR_INVALID_ARGUMENT;
+int vrc_pin_host_buffer(void *p, size_t bytes) {
+    if (!p || !bytes) return VRC_ERR_INVALID_ARGUMENT;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? VRC_OK : VRC_ERR_DEVICE;
+}
+int vrc_unpin_host_buffer(void *p) {
+    if (!p) return VRC_ERR_INVALID_ARGUMENT;
+    return hipHostUnregister(p) == hipSuccess ? VRC_OK : VRC_ERR_DEVICE;
+}
+
+int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out) {
+    if (!h || !out || rank < 0 || rank > (int32_t)h->peers.size()) return VRC_ERR_INVALID_ARGUMENT;
+    const vrc_caster *q = rank == 0 ? h : h->peers[rank - 1];
     memset(out, 0, sizeof(*out));
+    const size_t npix = q->d_viewport ? (size_t)q->width * (size_t)std::max(q->buffer_rows, 1) : 0;
+    out->device = q->device;
+    out->rows = q->buffer_rows;
+    out->viewport_bytes = 16 * npix;
+    out->image_bytes = 16 * npix;
+    out->hit_bytes = q->d_hits ? 32 * npix : 0;
+    out->octree_bytes = q->d_desc ? q->n_desc * 8 + (q->d_attach_lookup ? q->n_desc * 4 + std::max<uint64_t>(q->n_attach, 1) * 8 : 0) : 0;
+    out->octree_shared = q->owns_desc ? 0 : 1;
+    return VRC_OK;
+}
+
+}  // extern "C"
+
+namespace {
+int counters_one(vrc_caster *h, unsigned long long c[vrc::kCtrCount]) {
     if (!h->d_partials || h->last_blocks <= 0) return fail(h, VRC_ERR_NOT_READY, "get_counters: no frame computed");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, vrc::launch_reduce_counters(h->d_partials, h->last_blocks, h->d_counters, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    unsigned long long c[vrc::kCtrCount];
-    HIP_TRY(h, hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(c, h->d_counters, sizeof(unsigned long long) * vrc::kCtrCount, hipMemcpyDeviceToHost));
+    return VRC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vrc_get_counters(vrc_caster *h, vrc_counters *out) {
+    if (!h || !out) return VRC_ERR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    unsigned long long c[vrc::kCtrCount], t[vrc::kCtrCount];
+    int rc = counters_one(h, c);
+    if (rc != VRC_OK) return rc;
+    for (size_t i = 0; i < h->peers.size(); i++) {                 // a group reports the whole frame
+        rc = counters_one(h->peers[i], t);
+        if (rc != VRC_OK) return fail(h, rc, "rank %zu: %s", i + 1, h->peers[i]->error.c_str());
+        for (int k = 0; k < vrc::kCtrCount; k++) c[k] += t[k];
+    }
+    if (!h->peers.empty()) HIP_TRY(h, hipSetDevice(h->device));
     out->primary_rays = c[vrc::kCtrPrimary]; out->shadow_rays = c[vrc::kCtrShadow];
     out->descriptor_reads = c[vrc::kCtrDesc]; out->texel_reads = c[vrc::kCtrTex];
     out->map_reads = c[vrc::kCtrMap]; out->steps = c[vrc::kCtrSteps];
@@ -608,14 +1010,18 @@ int vrc_timing_reset(vrc_caster *h) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     int rc = vrc_sync(h);
     h->timed_launches = 0; h->timed_ms = 0.0;
+    for (vrc_caster *q : h->peers) { q->timed_launches = 0; q->timed_ms = 0.0; }
     return rc;
 }
 
+// a group reports rank 0's launch count and the largest per-rank kernel time (the critical path of the frame)
 int vrc_timing_get(vrc_caster *h, uint64_t *n_launches, double *total_kernel_ms) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     int rc = vrc_sync(h);
+    double ms = h->timed_ms;
+    for (vrc_caster *q : h->peers) ms = std::max(ms, q->timed_ms);
     if (n_launches) *n_launches = h->timed_launches;
-    if (total_kernel_ms) *total_kernel_ms = h->timed_ms;
+    if (total_kernel_ms) *total_kernel_ms = ms;
     return rc;
 }
 

@@ -43,7 +43,7 @@ struct RaycastParams {
     const float *viewport;            // float4[w*h]
     // arg 8: offline pixel buffer + hit records
     float *image;                     // float4[w*h]
-    int32_t *hits;                    // int32[8*w*h]
+    int32_t *hits;                    // int32[8*w*h]; nullptr = no hit records (setting hit_records = 0)
     // arg 9-11: atlas
     const uint8_t *atlas;             // RGBA8
     int32_t atlas_w, atlas_h;
@@ -81,7 +81,13 @@ struct RaycastParams {
     int32_t tile_rank, tile_world, band_tiles;   // band_tiles = band_rows / kTileH
     int32_t blocks_x;                 // ceil(width / 32)
     int32_t local_tile_rows;          // tile rows this rank renders
+    // 1: viewport / image / hits hold only this rank's rows (vrc_set_row_slice): row index = position among the
+    // rank's rows; 0: full-frame buffers indexed by the image row
+    int32_t row_sliced;
+    int32_t stepping_mode;            // 0: exact per-voxel DDA (reference parity); 1: node-exit jumps (SURVEY D1 mode B)
     unsigned long long *counters;
+    // host-mapped flag the round watchdog raises (checked by vrc_sync: a truncated frame never looks like success)
+    unsigned int *watchdog_flag;
 };
 
 }  // namespace vrc
