@@ -453,6 +453,86 @@ static int light_from_strike(const orc_scene *s, const float *L, const orc_strik
     return 1;
 }
 
+/* ---- stepping mode 1, "mode B" of SURVEY 7 D1: the node-sized jump the reference's unfinished octree branch was
+ * heading for (ray_caster_kernel.cl:525-540: intersection_t += delta_t * jump_power * fabs(face_mask), with the
+ * correction of the other axes commented out), done the stateless way: the exit of the ray  origin + t * ray_dir
+ * from the empty node [corner, corner + size)^3 it is in is  t = min_a (plane_a - origin_a) * (1 / ray_dir_a);
+ * the axes that reach the minimum cross to the neighbouring voxel, the others land on floor(origin_a + t * ray_dir_a)
+ * clamped into the node.  NOT the reference's float sequence (the reference accumulates intersection_t by repeated
+ * addition): a different renderer that agrees with the exact mode on nearly all hit voxels; this restatement is what
+ * the HIP jump kernel is bit-exact against.  Definitions the two share:
+ *   - steps of a jump = |dx| + |dy| + |dz| of the voxel (what the per-voxel loop would count, ties aside); the :357
+ *     guard ends the ray inside the node when the cap falls into the jump;
+ *   - on a hit the intersection_t the hit block (:586-618) reads is rebuilt from the exit: t + delta_t on the axes
+ *     that crossed, the ray's next crossing of the hit voxel's far plane on the others;
+ *   - a restarted ray (shadow / mirror) starts where the reference's restart arithmetic puts it (jump_restart_ray)
+ *     and jumps out of the single voxel it starts in first;
+ *   - the reference's octree bias (:353-354) has no counterpart (it biases an accumulated intersection_t).        */
+typedef struct {
+    float origin[3];
+    float inv[3];            /* 1 / ray_dir */
+    int   corner[3];
+    int   size;              /* the empty node the voxel is in; 1 = extent unknown */
+} jump_state;
+
+static void jump_set_ray(jump_state *j, const float origin[3], const float rd[3]) {
+    for (int a = 0; a < 3; a++) { j->origin[a] = origin[a]; j->inv[a] = 1.0f / rd[a]; }
+}
+/* A restarted ray (:677-679 shadow, :700-702 mirror).  The reference sets intersection_t = delta_t * frac(hit_pos) *
+ * voxel_step (+ delta_t where negative): the distance to the next plane is frac for rays going up an axis and 1 - frac
+ * for rays going down -- the mirror image of the geometric one (the primary set-up :313-323 has it right).  Its shadow
+ * and mirror rays therefore behave as if they started from hit_pos mirrored inside the restart voxel; mode B starts
+ * them exactly there, so it follows the reference's rays, not the geometrically intended ones.                      */
+static void jump_restart_ray(jump_state *j, const float hit_pos[3], const int voxel[3], const float rd[3]) {
+    float o[3];
+    for (int a = 0; a < 3; a++) o[a] = (float)voxel[a] + (1.0f - (hit_pos[a] - floorf(hit_pos[a])));
+    jump_set_ray(j, o, rd);
+}
+static void jump_set_node(jump_state *j, const int voxel[3], int size) {
+    for (int a = 0; a < 3; a++) j->corner[a] = voxel[a] & ~(size - 1);
+    j->size = size;
+}
+/* leaves the node: updates voxel, face_mask, returns the number of voxel steps */
+static int jump_step(const jump_state *j, const float rd[3], const int vstep[3], int voxel[3], int face_mask[3], float *t_exit) {
+    float tx[3];
+    for (int a = 0; a < 3; a++) {
+        const int plane = vstep[a] > 0 ? j->corner[a] + j->size : j->corner[a];
+        tx[a] = ((float)plane - j->origin[a]) * j->inv[a];
+    }
+    float t = tx[0];
+    if (tx[1] < t) t = tx[1];
+    if (tx[2] < t) t = tx[2];
+    int steps = 0;
+    for (int a = 0; a < 3; a++) {
+        int to;
+        face_mask[a] = tx[a] <= t;
+        if (face_mask[a]) {
+            to = vstep[a] > 0 ? j->corner[a] + j->size : j->corner[a] - 1;
+        } else {
+            const float p = j->origin[a] + t * rd[a];
+            to = (int)floorf(p);
+            if (to < j->corner[a]) to = j->corner[a];
+            if (to > j->corner[a] + j->size - 1) to = j->corner[a] + j->size - 1;
+        }
+        steps += to > voxel[a] ? to - voxel[a] : voxel[a] - to;
+        voxel[a] = to;
+    }
+    *t_exit = t;
+    return steps;
+}
+/* the intersection_t of a ray that has just entered `voxel` at parameter t through the faces in face_mask */
+static void jump_hit_intersection(const jump_state *j, const int vstep[3], const int voxel[3], const int face_mask[3], float t,
+                                  const float delta_t[3], float it[3]) {
+    for (int a = 0; a < 3; a++) {
+        if (face_mask[a]) {
+            it[a] = t + delta_t[a];
+        } else {
+            const int plane = vstep[a] > 0 ? voxel[a] + 1 : voxel[a];
+            it[a] = ((float)plane - j->origin[a]) * j->inv[a];
+        }
+    }
+}
+
 /* ---- one pixel of `raycaster`  (kernels/ray_caster_kernel.cl:256-724) */
 static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias[3],
                           float *image, int32_t *hits, orc_counters *ctr) {
@@ -516,9 +596,14 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
     /* :342-354 get_oct_vox(camera voxel) is pixel-independent: the bias
      * (sub_oct_pos - voxel) * resolution / 2 is evaluated once per frame by
      * the caller; its descriptor reads are charged per ray below.            */
-    for (int a = 0; a < 3; a++) it[a] += (float)bias[a];
-
     const int svo = (s->using_octree == 0);
+    const int jump = svo && s->stepping_mode == 1;
+    if (!jump)
+        for (int a = 0; a < 3; a++) it[a] += (float)bias[a];
+    jump_state js;
+    memset(&js, 0, sizeof(js));
+    js.size = 1;
+
     svo_cursor cur;
     uint32_t ndesc = 0;
     if (svo) {
@@ -528,8 +613,13 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
          * cursor's first descent (only meaningful when the camera is inside
          * the map; otherwise only the root read is charged)                  */
         if (voxel[0] >= 0 && voxel[1] >= 0 && voxel[2] >= 0 && voxel[0] < s->map_dim[0] &&
-            voxel[1] < s->map_dim[1] && voxel[2] < s->map_dim[2])
-            (void)svo_locate(&cur, voxel);
+            voxel[1] < s->map_dim[1] && voxel[2] < s->map_dim[2]) {
+            const int solid = svo_locate(&cur, voxel);
+            if (jump) jump_set_node(&js, voxel, solid ? 1 : 1 << (cur.n - cur.top - 1));
+        } else if (jump) {
+            jump_set_node(&js, voxel, 1);
+        }
+        if (jump) jump_set_ray(&js, s->cam_pos, rd);
     }
 
     /* the reference reads light 0 only (:660-670); active_lights > 1 is the multi-light extension */
@@ -542,6 +632,21 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
 
     for (;;) {
     while (distance_traveled < max_distance && bounce_count < 2) {        /* :357 */
+        float t_exit = 0.0f;
+        if (jump) {
+            /* mode B: one node-exit jump = `steps` iterations of the loop; the iteration that lands in the new voxel
+             * is this one, the steps before it only count (and may run into the :357 guard inside the node) */
+            int old[3] = {voxel[0], voxel[1], voxel[2]};
+            const int steps = jump_step(&js, rd, vstep, voxel, face_mask, &t_exit);
+            if (distance_traveled + steps - 1 >= max_distance) {
+                ctr->n_steps += (uint64_t)(max_distance - distance_traveled);
+                distance_traveled = max_distance;
+                voxel[0] = old[0]; voxel[1] = old[1]; voxel[2] = old[2];
+                continue;
+            }
+            ctr->n_steps += (uint64_t)steps;
+            distance_traveled += steps - 1;
+        } else {
         ctr->n_steps++;
         /* :558 ties step several axes */
         face_mask[0] = it[0] <= fmin_cl(it[1], it[2]);
@@ -550,6 +655,7 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
         for (int a = 0; a < 3; a++) {
             it[a] += delta_t[a] * (float)face_mask[a];            /* :559 */
             voxel[a] += vstep[a] * face_mask[a];                  /* :560 */
+        }
         }
         /* :563-568 */
         if (voxel[0] >= s->map_dim[0] || voxel[1] >= s->map_dim[1] || voxel[2] >= s->map_dim[2] ||
@@ -563,6 +669,10 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
         }
         if (svo) {
             voxel_data = svo_locate(&cur, voxel) ? 5 : 0;
+            if (jump) {
+                if (voxel_data) jump_hit_intersection(&js, vstep, voxel, face_mask, t_exit, delta_t, it);
+                jump_set_node(&js, voxel, voxel_data ? 1 : 1 << (cur.n - cur.top - 1));
+            }
             /* extension: material from the attachment buffers the reference
              * allocates but never reads; only bottom-level descriptors carry materials */
             if (voxel_data && s->attachment_lookup && s->attachments && cur.top == cur.n - 1) {
@@ -654,6 +764,12 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
                 }
                 ctr->shadow_rays++;
                 flags |= ORC_FLAG_SHADOW_CAST;
+                if (jump) {                   /* the restarted ray starts at hit_pos, in a voxel of unknown surroundings */
+                    const float hp[3] = {(float)strike.voxel[0] + strike.face_position[0], (float)strike.voxel[1] + strike.face_position[1],
+                                         (float)strike.voxel[2] + strike.face_position[2]};
+                    jump_restart_ray(&js, hp, voxel, rd);
+                    jump_set_node(&js, voxel, 1);
+                }
             } else if (voxel_data == 6 && !shadow_ray) {          /* :682-704 */
                 int tx = (int)(tile_face_position[0] * (float)tiles_x) + (int)(3.0f * (float)tiles_x);
                 int ty = (int)(tile_face_position[1] * (float)tiles_y) + (int)(4.0f * (float)tiles_y);
@@ -682,6 +798,10 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
                     it[a] += delta_t[a] * -(it[a] < 0.0f ? -1.0f : 0.0f);
                 }
                 bounce_count += 1;
+                if (jump) {
+                    jump_restart_ray(&js, hit_pos, voxel, rd);
+                    jump_set_node(&js, voxel, 1);
+                }
             } else {                                              /* :707-710 */
                 color_accumulator[3] = 0.1f;
                 flags |= ORC_FLAG_SHADOW_HIT;
@@ -702,6 +822,12 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
         }
         ctr->shadow_rays++;
         distance_traveled = strike.distance + 1;      /* as if the strike iteration had just finished (:714) */
+        if (jump) {
+            const float hp[3] = {(float)strike.voxel[0] + strike.face_position[0], (float)strike.voxel[1] + strike.face_position[1],
+                                 (float)strike.voxel[2] + strike.face_position[2]};
+            jump_restart_ray(&js, hp, voxel, rd);
+            jump_set_node(&js, voxel, 1);
+        }
     }
 
     {

@@ -125,6 +125,8 @@ typedef struct {
     int32_t         active_lights;       /* <= 1: light 0 only (the reference); n: the first n lights, each
                                             from the first strike (see light_from_strike)       */
     float           cam_trig[4];         /* sin(dir.x) cos(dir.x) sin(dir.y) cos(dir.y) */
+    int32_t         stepping_mode;       /* 0: the reference's per-voxel DDA (:558-560).  1: "mode B" (SURVEY D1), SVO only:
+                                            stateless node-exit jumps, see raycast_pixel / jump_step in vrc_oracle.c   */
     /* optional paged descriptor source (see ORC_PAGE_SIZE): when desc_page_fetch is set, `descriptors` is not read;
      * desc_pages is a zero-initialised table of ceil(n_descriptors / ORC_PAGE_SIZE) pointers the oracle fills */
     const uint64_t  **desc_pages;

@@ -102,4 +102,23 @@ def with_lights(s, n):
     return out
 
 
+def shadow_box(dim=32):
+    """A block on a floor, the light behind and above it, the camera close in front: the reference kernel's hard-coded
+    20-step cap (ray_caster_kernel.cl:326) is enough to reach the floor, the block and the block's shadow."""
+    g = _grid(dim)
+    g[0:2, :, :] = 5
+    g[2:10, 14:20, 14:20] = 5
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, 16.5, 26.5, 12.5, -1, -1, -1.5]], dtype=np.float32)
+    return dict(name=f"shadow_box{dim}", dim=dim, grid=g.reshape(-1), cam_pos=(16.37, 5.41, 6.29), cam_dir=(2.2, 1.5708), lights=lights)
+
+
+def near_mirror(dim=32):
+    """mirror_wall from six voxels in front of the mirror: bounce, then floor / pillar hits within 20 steps."""
+    s = mirror_wall(dim)
+    s.update(name=f"near_mirror{dim}", cam_pos=(dim * 0.5 + 0.21, dim - 10.57, 4.37), cam_dir=(1.9, 1.5708))
+    return s
+
+
 ALL = [app_default, floor_pillars, mirror_wall, open_sky, axis_aligned, random_sparse]
+# the scenes the reference's own kernel is run on (tests/test_reference_pin_gpu.py): its step cap is 20
+REFERENCE_KERNEL_SCENES = ALL + [shadow_box, near_mirror]

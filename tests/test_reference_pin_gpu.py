@@ -148,8 +148,8 @@ def run_reference_raycaster(probe, code_object, s, w, h, atlas):
     return rec, trig, buf, root
 
 
-@pytest.mark.parametrize("make", scenes.ALL, ids=[f.__name__ for f in scenes.ALL])
-@pytest.mark.parametrize("res", [(64, 48), (160, 120)], ids=["64x48", "160x120"])
+@pytest.mark.parametrize("make", scenes.REFERENCE_KERNEL_SCENES, ids=[f.__name__ for f in scenes.REFERENCE_KERNEL_SCENES])
+@pytest.mark.parametrize("res", [(64, 48), (640, 480)], ids=["64x48", "640x480"])
 def test_reference_raycaster_step_loop_against_the_oracle(probe, make, res, atlas):
     """SURVEY 8c G3 scenes (camera inside solid, pillars + shadows, mirror wall, rays leaving the map, axis-aligned rays
     with unwritten pixels, random grid).  IEEE build of the reference kernel (no fast-math, no contraction, correctly
@@ -164,7 +164,7 @@ def test_reference_raycaster_step_loop_against_the_oracle(probe, make, res, atla
     rec, trig, buf, root = run_reference_raycaster(probe, "ref_raycaster_gfx950_strict.co", s, w, h, atlas)
     oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=s["lights"], atlas=atlas,
                                     tile_dim=(16, 16), descriptors=buf, root_index=root, octree_dim=s["dim"], using_octree=1,
-                                    grid=s["grid"], max_distance=20, trig=trig)
+                                    grid=s["grid"], max_distance=20, trig=trig, threads=8)
     written = rec[..., 15] == 1
     # pixels the kernel returned from without writing (:293-294, :671-672, :694-695)
     assert np.array_equal(written, (ohits[..., 5] & 1) == 1), "written / unwritten pixels differ"
@@ -207,12 +207,12 @@ def test_reference_raycaster_with_the_references_own_flags(probe, atlas):
     if not os.path.exists(os.path.join(REF, "ref_raycaster_gfx950.co")):
         pytest.skip("oracle/_ref/ref_raycaster_gfx950.co not built")
     lines = []
-    for make in scenes.ALL:
-        s, (w, h) = make(), (160, 120)
+    for make in scenes.REFERENCE_KERNEL_SCENES:
+        s, (w, h) = make(), (640, 480)
         rec, trig, buf, root = run_reference_raycaster(probe, "ref_raycaster_gfx950.co", s, w, h, atlas)
         oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=s["lights"], atlas=atlas,
                                      tile_dim=(16, 16), descriptors=buf, root_index=root, octree_dim=s["dim"], using_octree=1,
-                                     grid=s["grid"], max_distance=20, trig=trig)
+                                     grid=s["grid"], max_distance=20, trig=trig, threads=8)
         hit = rec[..., 16] > 0
         both = hit & (ohits[..., 3] != 0)
         same_voxel = (rec[..., 17:20][both] == ohits[..., 0:3][both]).all(-1)

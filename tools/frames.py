@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Renders N frames of the headline workload in a given stepping mode (for rocprofv3: no compiler, no oracle, no child
+process is ever started from here).  python3 tools/frames.py --mode 1 --frames 10 [--hit-records 0]"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--mode", type=int, default=0)
+ap.add_argument("--frames", type=int, default=10)
+ap.add_argument("--depth", type=int, default=12)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--lights", type=int, default=1)
+ap.add_argument("--hit-records", type=int, default=1)
+ap.add_argument("--set", action="append", default=[], help="name=value setting overrides")
+a = ap.parse_args()
+sc = bench.build_scene(a.depth)
+c = bench.make_caster(sc, a.width, a.height, 0, light_count=a.lights, hit_records=a.hit_records)
+assert c.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", a.mode)
+for kv in a.set:
+    k, v = kv.split("=")
+    assert c.add_to_settings_buffer(k, k.upper(), int(v))
+for _ in range(2):
+    assert c.compute(), c.last_error()
+c.timing_reset()
+for _ in range(a.frames):
+    assert c.compute(), c.last_error()
+n, ms = c.timing()
+ctr = c.counters()
+b = bench.algorithmic_bytes(ctr, a.width * a.height, a.width * a.height - ctr["unwritten_pixels"])
+print(json.dumps({"mode": a.mode, "kernel_ms_avg": round(ms / n, 4), "rays": ctr["primary_rays"] + ctr["shadow_rays"],
+                  "Mrays_s": round((ctr["primary_rays"] + ctr["shadow_rays"]) / (ms / n) / 1e3, 1), "algorithmic_bytes": b,
+                  "GB_s": round(b / (ms / n) / 1e6, 1), "counters": ctr}))

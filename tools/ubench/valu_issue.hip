@@ -1,0 +1,95 @@
+// Micro-benchmark (round 2): VALU issue cost per wave64 instruction on gfx950, measured in SHADER CYCLES with s_memtime
+// inside the kernel (not wall time at the nominal clock: a chip-filling VALU loop runs far below 2.4 GHz under DVFS, which
+// is what made profiles/r01_valu_issue_rate.txt read "3 cycles" for v_fma_f32).  For each instruction class: W waves per
+// SIMD (1, 2, 4, 8), 8 independent dependency chains per wave, 64 x 16 instructions between two s_memtime reads; the
+// figure is (cycles of the slowest wave on the SIMD) * / (instructions issued by all W waves of that SIMD), i.e. the
+// SIMD's issue interval.  Also prints wall-clock derived "cycles at 2.4 GHz" so the two views can be compared, and the
+// effective clock = shader cycles / wall time.
+//   hipcc --offload-arch=gfx950 -O2 tools/ubench/valu_issue.hip -o tools/ubench/valu_issue && tools/ubench/valu_issue
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+#define REP8(x) x x x x x x x x
+#define BODY(OP)                                                                                           \
+    REP8(asm volatile(OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)                                       \
+                      : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k0), "v"(k1));)
+
+#define DEFK(name, OP)                                                                                     \
+__global__ __launch_bounds__(256) void k_##name(float *out, unsigned long long *cyc, int iters) {          \
+    float r0 = threadIdx.x + 1.0f, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7; \
+    float k0 = 1.0001f, k1 = 0.5f;                                                                          \
+    const unsigned long long t0 = __builtin_readcyclecounter();                                             \
+    for (int i = 0; i < iters; i++) { BODY(OP) }                                                            \
+    const unsigned long long t1 = __builtin_readcyclecounter();                                             \
+    out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;                            \
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                       \
+}
+
+#define OP_FMA(i)    "v_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_ADD(i)    "v_add_f32 %" #i ", %" #i ", %9\n"
+#define OP_MUL(i)    "v_mul_f32 %" #i ", %" #i ", %8\n"
+#define OP_FMAC(i)   "v_fmac_f32 %" #i ", %8, %9\n"
+#define OP_FMACL(i)  "v_fma_f32 %" #i ", %" #i ", %8, %9 clamp\n"
+#define OP_MIN(i)    "v_min_f32 %" #i ", %" #i ", %9\n"
+#define OP_MIN3(i)   "v_min3_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_MAX(i)    "v_max_f32 %" #i ", %" #i ", %9\n"
+#define OP_CMP(i)    "v_cmp_le_f32 vcc, %" #i ", %9\n"
+#define OP_CNDS(i)   "v_cndmask_b32 %" #i ", %" #i ", %8, s[20:21]\n"
+#define OP_CVT(i)    "v_cvt_i32_f32 %" #i ", %" #i "\n"
+#define OP_ADDU(i)   "v_add_u32 %" #i ", %" #i ", %9\n"
+#define OP_AND(i)    "v_and_b32 %" #i ", %" #i ", %9\n"
+#define OP_LSHL(i)   "v_lshlrev_b32 %" #i ", 1, %" #i "\n"
+#define OP_MOV(i)    "v_mov_b32 %" #i ", %9\n"
+#define OP_RCP(i)    "v_rcp_f32 %" #i ", %" #i "\n"
+#define OP_MADU(i)   "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
+#define OP_BFE(i)    "v_bfe_u32 %" #i ", %" #i ", 3, 5\n"
+#define OP_SUB(i)    "v_sub_f32 %" #i ", %" #i ", %9\n"
+
+DEFK(fma, OP_FMA) DEFK(add, OP_ADD) DEFK(mul, OP_MUL) DEFK(fmac, OP_FMAC) DEFK(fmaclamp, OP_FMACL) DEFK(minf, OP_MIN)
+DEFK(min3, OP_MIN3) DEFK(maxf, OP_MAX) DEFK(cmp, OP_CMP) DEFK(cnds, OP_CNDS) DEFK(cvt, OP_CVT) DEFK(addu, OP_ADDU)
+DEFK(andb, OP_AND) DEFK(lshl, OP_LSHL) DEFK(mov, OP_MOV) DEFK(rcp, OP_RCP) DEFK(madu, OP_MADU) DEFK(bfe, OP_BFE) DEFK(sub, OP_SUB)
+
+typedef void (*kern_t)(float *, unsigned long long *, int);
+
+int main() {
+    struct { const char *name; kern_t k; } ks[] = {
+        {"v_fma_f32", k_fma}, {"v_add_f32", k_add}, {"v_sub_f32", k_sub}, {"v_mul_f32", k_mul}, {"v_fmac_f32", k_fmac},
+        {"v_fma_f32 clamp", k_fmaclamp}, {"v_min_f32", k_minf}, {"v_min3_f32", k_min3}, {"v_max_f32", k_maxf},
+        {"v_cmp_le_f32 vcc", k_cmp}, {"v_cndmask_b32 (sgpr)", k_cnds}, {"v_cvt_i32_f32", k_cvt}, {"v_add_u32", k_addu},
+        {"v_and_b32", k_andb}, {"v_lshlrev_b32", k_lshl}, {"v_mov_b32", k_mov}, {"v_rcp_f32", k_rcp},
+        {"v_mad_u32_u24", k_madu}, {"v_bfe_u32", k_bfe}};
+    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    const int iters = 256;                                  // 256 x 64 = 16384 instructions per wave between the two clock reads
+    float *out; hipMalloc(&out, sizeof(float) * cus * 8 * 256);
+    unsigned long long *cyc; hipMalloc(&cyc, sizeof(unsigned long long) * cus * 8 * 4);
+    std::vector<unsigned long long> h(cus * 8 * 4);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    printf("# %s, %d CUs, nominal clock %d kHz.  Per class and W = waves per SIMD: issue interval in SHADER cycles per wave64\n"
+           "# instruction (median over waves of: s_memtime delta * / (16384 * W)); [wall-clock cycles at the nominal clock]; (effective GHz)\n",
+           prop.name, cus, prop.clockRate);
+    for (auto &e : ks) {
+        printf("%-22s", e.name);
+        for (int w = 1; w <= 8; w *= 2) {
+            const int blocks = cus * w;                     // w blocks of 4 waves per CU = w waves per SIMD
+            e.k<<<blocks, 256>>>(out, cyc, 8);
+            hipDeviceSynchronize();
+            hipEventRecord(a);
+            e.k<<<blocks, 256>>>(out, cyc, iters);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * blocks * 4, hipMemcpyDeviceToHost);
+            std::sort(h.begin(), h.begin() + blocks * 4);
+            const double med = (double)h[blocks * 2];
+            const double insts = (double)iters * 64.0;
+            const double shader = med / (insts * w);
+            const double wall = ms * 1e-3 * prop.clockRate * 1e3 / (insts * w);
+            printf("  W=%d %5.2f [%5.2f] (%.2f)", w, shader, wall, med / (ms * 1e6));
+        }
+        printf("\n");
+    }
+    return 0;
+}

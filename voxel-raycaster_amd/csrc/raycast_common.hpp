@@ -76,6 +76,7 @@ struct Ray {
     int kmx, kmy, kmz;                   // face_mask * voxel_step of the primary ray
     int kdist;                           // distance_traveled at the strike
     int light_index;
+    float hpx, hpy, hpz;                 // hit_pos of the last redirect (read by the node-exit jump kernel only)
 };
 
 // :276-323 + the frame-constant bias of :342-354.  Returns false for the
@@ -266,6 +267,7 @@ __device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastP
         r.bounce_count += 1;
     }
     restart_from(r, hit_pos);                                                 // :677-679 / :700-702
+    r.hpx = hit_pos.x; r.hpy = hit_pos.y; r.hpz = hit_pos.z;
     return false;
 }
 

@@ -1,4 +1,244 @@
-// placeholder, replaced below
+// raycast_jump_kernel.hip -- stepping mode 1 ("mode B" of SURVEY 7 D1), the memory-side twin of the exact kernel.
+//
+// The reference's unfinished octree branch was heading for node-sized jumps (kernels/ray_caster_kernel.cl:525-540:
+// intersection_t += delta_t * jump_power * fabs(face_mask), the correction of the other axes commented out).  This
+// kernel does that jump the stateless way: the exit of  origin + t * ray_dir  from the empty node it is in is
+// t = min_a (plane_a - origin_a) / ray_dir_a.  One node event costs ~100 instructions instead of ~120 DDA steps, so
+// the frame is bound by the descriptor chain (dependent 8-byte loads), not by VALU issue: this is the mode that puts
+// the memory-side design under load.  It is NOT the reference's float sequence (the reference accumulates
+// intersection_t by repeated addition and the hit block reads the accumulated rounding back, :592-614), so it is a
+// labelled, opt-in mode (setting stepping_mode = 1), never the headline: its parity statement is bit-exactness against
+// its own restatement in oracle/vrc_oracle.c (jump_step & co, same definitions, cited there) plus mismatch statistics
+// against the exact mode on every bench frame.
+//
+// Shared with the exact kernel: ray set-up, hit block, epilogue (raycast_common.hpp), the packed LDS traversal stack
+// [level][thread], deferred shading with wave votes, the XCD-aware block -> tile map, per-block counter partials.
 #include <hip/hip_runtime.h>
-#include "vrc_params.h"
-namespace vrc { hipError_t launch_raycast_jump(const RaycastParams &, hipStream_t) { return hipErrorNotSupported; } }
+
+#include "raycast_common.hpp"
+
+namespace vrc {
+
+namespace {
+__device__ __forceinline__ uint64_t jump_make_entry(const uint64_t *__restrict__ descriptors, uint64_t index, uint64_t d) {
+    uint64_t base = index + (d & 0x7fffULL);
+    if (d & 0x8000ULL) base = descriptors[base];          // far pointer: slot holds an absolute index
+    return (base << 16) | ((d >> 16) & 0xffffULL);
+}
+enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3 };
+}  // namespace
+
+#ifndef VRC_JUMP_MIN_BLOCKS
+#define VRC_JUMP_MIN_BLOCKS (24 / VRC_TILES_PER_BLOCK)
+#endif
+
+template <bool kMulti>
+__global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_jump_kernel(const RaycastParams p) {
+    extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
+    __shared__ unsigned long long block_ctr[kCtrCount];
+    const int tid = threadIdx.x;
+    if (tid < kCtrCount) block_ctr[tid] = 0;
+    __syncthreads();
+
+    int px, py, brow;
+    block_pixel(p, px, py, brow);
+    const bool in_image = px < p.width && py < p.height;
+    const long pix = (long)px + (long)p.width * brow;
+
+    Ray r;
+    unsigned c_primary = 0, c_desc = 0, c_unwritten = 0, c_steps = 0;
+    int mode = jDone, mat = 5;
+    auto ended = [&]() -> int { return (kMulti && more_lights(r, p)) ? jRelight : jDone; };
+
+    // the ray as a line: origin + t * ray_dir, and the empty node [corner, corner + size)^3 the voxel is in
+    float ox = 0.f, oy = 0.f, oz = 0.f, ivx = 0.f, ivy = 0.f, ivz = 0.f;
+    int cx = 0, cy = 0, cz = 0, size = 1;
+    float t_exit = 0.0f;
+
+    const int n = p.log2_dim;
+    const uint64_t *__restrict__ descriptors = p.descriptors;
+    uint64_t root_entry = 0, cur = 0;
+    int top = 0, pvx = 0, pvy = 0, pvz = 0;
+
+    // returns b >= 0: voxel lies in an empty node of size 2^b;  -1: voxel is solid   (canonical traversal)
+    auto locate = [&](int x, int y, int z) -> int {
+        const unsigned diff = (unsigned)((x ^ pvx) | (y ^ pvy) | (z ^ pvz));
+        if (top > 0 && (diff >> (n - top)) != 0) {
+            top = n - (31 - __clz((int)diff)) - 1;
+            cur = (top == 0) ? root_entry : lds_stack[(top - 1) * kBlockThreads + tid];
+        }
+        pvx = x; pvy = y; pvz = z;
+        for (;;) {
+            const int b = n - top - 1;
+            const int i = ((x >> b) & 1) | (((y >> b) & 1) << 1) | (((z >> b) & 1) << 2);
+            const unsigned masks = (unsigned)cur & 0xffffu;
+            const unsigned bit = 1u << i;
+            if (!(masks & bit)) return b;
+            if (((masks >> 8) & bit) || b == 0) return -1;
+            const uint64_t child = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
+            const uint64_t d = descriptors[child];
+            c_desc++;
+            cur = jump_make_entry(descriptors, child, d);
+            lds_stack[top * kBlockThreads + tid] = cur;
+            top++;
+        }
+    };
+    auto solid_material = [&](int x, int y, int z) -> int {
+        if (!p.attach_lookup || top != n - 1) return 5;
+        uint64_t node = p.root_index;
+        if (top > 0) {
+            const uint64_t parent = (top == 1) ? root_entry : lds_stack[(top - 2) * kBlockThreads + tid];
+            const int slot = ((x >> 1) & 1) | (((y >> 1) & 1) << 1) | (((z >> 1) & 1) << 2);
+            node = (parent >> 16) + (uint64_t)(__popc((unsigned)parent & 0xffu & ((2u << slot) - 1u)) - 1);
+        }
+        const uint64_t a = p.attachments[p.attach_lookup[node]];
+        return (int)(int8_t)(a >> (8 * ((x & 1) | ((y & 1) << 1) | ((z & 1) << 2))));
+    };
+    auto set_node = [&](int s) {
+        size = s;
+        cx = r.vx & ~(s - 1); cy = r.vy & ~(s - 1); cz = r.vz & ~(s - 1);
+    };
+    auto set_ray = [&](float x, float y, float z) {
+        ox = x; oy = y; oz = z;
+        ivx = 1.0f / r.rdx; ivy = 1.0f / r.rdy; ivz = 1.0f / r.rdz;
+    };
+    // a restarted ray starts where the reference's restart arithmetic (:677-679, :700-702) puts it: hit_pos mirrored
+    // inside the restart voxel (oracle/vrc_oracle.c jump_restart_ray)
+    auto restart_ray = [&](float hx, float hy, float hz) {
+        set_ray((float)r.vx + (1.0f - (hx - floorf(hx))), (float)r.vy + (1.0f - (hy - floorf(hy))),
+                (float)r.vz + (1.0f - (hz - floorf(hz))));
+        set_node(1);
+    };
+
+    if (in_image) {
+        if (!ray_setup(r, p, pix)) {
+            c_unwritten = 1;
+        } else {
+            // ray_setup added the octree bias of :353-354 to intersection_t; this mode never reads intersection_t
+            c_primary = 1;
+            const uint64_t d = descriptors[p.root_index];
+            c_desc = 1;
+            root_entry = jump_make_entry(descriptors, p.root_index, d);
+            cur = root_entry;
+            int b = -1;
+            if (r.vx >= 0 && r.vy >= 0 && r.vz >= 0 && r.vx < p.map_dim[0] && r.vy < p.map_dim[1] && r.vz < p.map_dim[2])
+                b = locate(r.vx, r.vy, r.vz);
+            set_node(b >= 0 ? 1 << b : 1);
+            set_ray(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
+            mode = (r.distance_traveled < r.max_distance) ? jStep : jDone;    // :357 guard
+        }
+    }
+
+    const int shade_threshold = kDefaultShadeThreshold;
+    int rounds_left = p.watchdog_rounds;
+    for (;;) {
+        // ---- node-exit jump + lookup of the voxel the ray lands in
+        if (mode == jStep) {
+            const float plx = (float)(r.sx > 0 ? cx + size : cx), ply = (float)(r.sy > 0 ? cy + size : cy),
+                        plz = (float)(r.sz > 0 ? cz + size : cz);
+            const float tx = (plx - ox) * ivx, ty = (ply - oy) * ivy, tz = (plz - oz) * ivz;
+            float t = tx;
+            if (ty < t) t = ty;
+            if (tz < t) t = tz;
+            const int mx = tx <= t, my = ty <= t, mz = tz <= t;
+            int nx, ny, nz;
+            if (mx) nx = r.sx > 0 ? cx + size : cx - 1;
+            else { nx = (int)floorf(ox + t * r.rdx); nx = nx < cx ? cx : (nx > cx + size - 1 ? cx + size - 1 : nx); }
+            if (my) ny = r.sy > 0 ? cy + size : cy - 1;
+            else { ny = (int)floorf(oy + t * r.rdy); ny = ny < cy ? cy : (ny > cy + size - 1 ? cy + size - 1 : ny); }
+            if (mz) nz = r.sz > 0 ? cz + size : cz - 1;
+            else { nz = (int)floorf(oz + t * r.rdz); nz = nz < cz ? cz : (nz > cz + size - 1 ? cz + size - 1 : nz); }
+            const int steps = abs(nx - r.vx) + abs(ny - r.vy) + abs(nz - r.vz);
+            if (r.distance_traveled + steps - 1 >= r.max_distance) {     // the :357 guard ends the ray inside the node
+                c_steps += (unsigned)(r.max_distance - r.distance_traveled);
+                r.distance_traveled = r.max_distance;
+                mode = ended();
+            } else {
+                c_steps += (unsigned)steps;
+                r.distance_traveled += steps - 1;
+                r.vx = nx; r.vy = ny; r.vz = nz;
+                r.fmx = mx; r.fmy = my; r.fmz = mz;
+                t_exit = t;
+                if (nx >= p.map_dim[0] || ny >= p.map_dim[1] || nz >= p.map_dim[2] || nx < 0 || ny < 0 || nz < 0) {
+                    oob_exit(r);                              // :563-568
+                    mode = ended();
+                } else {
+                    const int b = locate(nx, ny, nz);
+                    if (b >= 0) {
+                        set_node(1 << b);
+                        r.distance_traveled++;                // :714
+                        mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
+                    } else {
+                        set_node(1);
+                        mat = solid_material(nx, ny, nz);
+                        if (mat == 5 || mat == 6) {           // :575
+                            // the intersection_t the hit block reads (:586-618), rebuilt from the exit
+                            r.itx = mx ? t + r.dtx : ((float)(r.sx > 0 ? nx + 1 : nx) - ox) * ivx;
+                            r.ity = my ? t + r.dty : ((float)(r.sy > 0 ? ny + 1 : ny) - oy) * ivy;
+                            r.itz = mz ? t + r.dtz : ((float)(r.sz > 0 ? nz + 1 : nz) - oz) * ivz;
+                            mode = jShade;                    // the hit block is deferred
+                        } else {                              // any other material is passed through
+                            r.distance_traveled++;
+                            mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long st = __ballot(mode == jStep);
+        const unsigned long long sh = __ballot(mode == jShade || (kMulti && mode == jRelight));
+        if ((st | sh) == 0ULL || --rounds_left < 0) break;
+
+        // ---- hit block (:575-711): runs when many lanes wait for it or nothing cheaper is left
+        if (sh != 0ULL && (st == 0ULL || __popcll(sh) >= shade_threshold)) {
+            if (kMulti && mode == jRelight) {                 // back to the first strike for the next light
+                r.light_index++;
+                if (!light_from_strike(r, p, r.light_index, true)) {
+                    mode = jDone;                             // :671-672, pixel left unwritten
+                } else {
+                    restart_from(r, strike_pos(r));
+                    const Vec3 hp = strike_pos(r);
+                    restart_ray(hp.x, hp.y, hp.z);
+                    r.distance_traveled = r.kdist + 1;        // as if the strike iteration had just finished (:714)
+                    mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
+                }
+            } else if (mode == jShade) {
+                if (hit_block<kMulti>(r, mat, p)) {
+                    mode = ended();
+                } else {
+                    restart_ray(r.hpx, r.hpy, r.hpz);
+                    r.distance_traveled++;                    // :714
+                    mode = (r.distance_traveled < r.max_distance && r.bounce_count < 2) ? jStep : ended();
+                }
+            }
+        }
+    }
+    (void)t_exit;
+
+    if (rounds_left < 0 && (tid & 63) == 0) {
+        atomicAdd(&block_ctr[kCtrWatchdog], 1ULL);
+        if (p.watchdog_flag) __hip_atomic_store(p.watchdog_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    unsigned c_tex = 0, c_shadow = 0;
+    if (in_image) {
+        if (c_primary) {
+            c_tex = r.c_tex; c_shadow = r.c_shadow;
+            if (!r.written) c_unwritten = 1;
+        }
+        ray_finish(r, p, pix, c_desc);
+    }
+    const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
+    publish_counters(p, block_ctr, vals);
+}
+
+hipError_t launch_raycast_jump(const RaycastParams &p, hipStream_t stream) {
+    const int nblocks = p.blocks_x * p.local_tile_rows;
+    if (nblocks <= 0) return hipSuccess;
+    const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
+    const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t);
+    if (p.light_count > 1) hipLaunchKernelGGL((raycast_jump_kernel<true>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+    else hipLaunchKernelGGL((raycast_jump_kernel<false>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace vrc
