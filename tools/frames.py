@@ -15,6 +15,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--lights", type=int, default=1)
 ap.add_argument("--hit-records", type=int, default=1)
 ap.add_argument("--set", action="append", default=[], help="name=value setting overrides")
+ap.add_argument("--streams", type=int, default=1, help="casters rendering concurrently (each its own HIP stream and buffers)")
 a = ap.parse_args()
 sc = bench.build_scene(a.depth)
 c = bench.make_caster(sc, a.width, a.height, 0, light_count=a.lights, hit_records=a.hit_records)
@@ -29,6 +30,22 @@ for _ in range(a.frames):
     assert c.compute(), c.last_error()
 n, ms = c.timing()
 ctr = c.counters()
+if a.streams > 1:
+    import time
+    cs = [c] + [bench.make_caster(sc, a.width, a.height, 0, light_count=a.lights, hit_records=a.hit_records) for _ in range(a.streams - 1)]
+    for q in cs[1:]:
+        assert q.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", a.mode)
+        for kv in a.set:
+            k, v = kv.split("=")
+            assert q.add_to_settings_buffer(k, k.upper(), int(v))
+        assert q.compute(), q.last_error()
+    t0 = time.perf_counter()
+    for _ in range(a.frames):
+        for q in cs:
+            assert q.compute_async()
+        for q in cs:
+            assert q.sync()
+    ms, n = (time.perf_counter() - t0) * 1e3, a.frames * a.streams
 b = bench.algorithmic_bytes(ctr, a.width * a.height, a.width * a.height - ctr["unwritten_pixels"])
 print(json.dumps({"mode": a.mode, "kernel_ms_avg": round(ms / n, 4), "rays": ctr["primary_rays"] + ctr["shadow_rays"],
                   "Mrays_s": round((ctr["primary_rays"] + ctr["shadow_rays"]) / (ms / n) / 1e3, 1), "algorithmic_bytes": b,

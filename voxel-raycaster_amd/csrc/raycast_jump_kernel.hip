@@ -25,11 +25,15 @@ __device__ __forceinline__ uint64_t jump_make_entry(const uint64_t *__restrict__
     if (d & 0x8000ULL) base = descriptors[base];          // far pointer: slot holds an absolute index
     return (base << 16) | ((d >> 16) & 0xffffULL);
 }
-enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3 };
+enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4 };
 }  // namespace
 
+// blocks per CU the register budget is set for: 7 waves per SIMD (72 VGPRs, a handful of spills) measured fastest --
+// 5 / 6 / 7 blocks: 0.93 / 0.91 / 0.85 ms on the headline frame; the kernel waits on dependent loads half of the time
+// (profiles/r02_pmc_mode_b.txt), so residency beats spill-free registers.  LDS (22.5 KB of stack per block at depth 12)
+// allows 7 blocks per CU as well.
 #ifndef VRC_JUMP_MIN_BLOCKS
-#define VRC_JUMP_MIN_BLOCKS (24 / VRC_TILES_PER_BLOCK)
+#define VRC_JUMP_MIN_BLOCKS (28 / VRC_TILES_PER_BLOCK)
 #endif
 
 template <bool kMulti>
@@ -132,7 +136,10 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
     const int shade_threshold = kDefaultShadeThreshold;
     int rounds_left = p.watchdog_rounds;
     for (;;) {
-        // ---- node-exit jump + lookup of the voxel the ray lands in
+        // One round = every live lane takes ONE step of its own chain: a node-exit jump (pure arithmetic + the pop to the
+        // common ancestor, an LDS read) and/or one level of the descent toward the voxel it landed in (one dependent 8-byte
+        // load).  Lanes do not wait for each other's descents: a wave needs as many rounds as its longest lane has loads,
+        // not the sum over events of the deepest descent among its lanes.
         if (mode == jStep) {
             const float plx = (float)(r.sx > 0 ? cx + size : cx), ply = (float)(r.sy > 0 ? cy + size : cy),
                         plz = (float)(r.sz > 0 ? cz + size : cz);
@@ -163,29 +170,46 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
                     oob_exit(r);                              // :563-568
                     mode = ended();
                 } else {
-                    const int b = locate(nx, ny, nz);
-                    if (b >= 0) {
-                        set_node(1 << b);
-                        r.distance_traveled++;                // :714
-                        mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
-                    } else {
-                        set_node(1);
-                        mat = solid_material(nx, ny, nz);
-                        if (mat == 5 || mat == 6) {           // :575
-                            // the intersection_t the hit block reads (:586-618), rebuilt from the exit
-                            r.itx = mx ? t + r.dtx : ((float)(r.sx > 0 ? nx + 1 : nx) - ox) * ivx;
-                            r.ity = my ? t + r.dty : ((float)(r.sy > 0 ? ny + 1 : ny) - oy) * ivy;
-                            r.itz = mz ? t + r.dtz : ((float)(r.sz > 0 ? nz + 1 : nz) - oz) * ivz;
-                            mode = jShade;                    // the hit block is deferred
-                        } else {                              // any other material is passed through
-                            r.distance_traveled++;
-                            mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
-                        }
+                    // pop to the deepest level whose node holds both the voxel located last and the new one (after a
+                    // redirect the two are not neighbours: the cursor still sits at the hit voxel)
+                    const unsigned diff = (unsigned)((nx ^ pvx) | (ny ^ pvy) | (nz ^ pvz));
+                    if (top > 0 && (diff >> (n - top)) != 0) {
+                        top = n - (31 - __clz((int)diff)) - 1;
+                        cur = (top == 0) ? root_entry : lds_stack[(top - 1) * kBlockThreads + tid];
                     }
+                    pvx = nx; pvy = ny; pvz = nz;
+                    mode = jDescend;
                 }
             }
         }
-        const unsigned long long st = __ballot(mode == jStep);
+        if (mode == jDescend) {
+            const int b = n - top - 1;
+            const int i = ((r.vx >> b) & 1) | (((r.vy >> b) & 1) << 1) | (((r.vz >> b) & 1) << 2);
+            const unsigned masks = (unsigned)cur & 0xffffu;
+            const unsigned bit = 1u << i;
+            if (!(masks & bit)) {                             // the voxel lies in an empty node of size 2^b
+                set_node(1 << b);
+                r.distance_traveled++;                        // :714
+                mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
+            } else if (((masks >> 8) & bit) || b == 0) {      // solid
+                set_node(1);
+                mat = solid_material(r.vx, r.vy, r.vz);
+                if (mat == 5 || mat == 6) {                   // :575
+                    mode = jShade;                            // the hit block is deferred
+                } else {                                      // any other material is passed through
+                    r.distance_traveled++;
+                    mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
+                }
+            } else {                                          // one level down: one dependent load
+                const uint64_t child = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
+                const uint64_t d = descriptors[child];
+                c_desc++;
+                cur = jump_make_entry(descriptors, child, d);
+                lds_stack[top * kBlockThreads + tid] = cur;
+                top++;
+            }
+        }
+        const unsigned long long st = __ballot(mode == jStep || mode == jDescend);
         const unsigned long long sh = __ballot(mode == jShade || (kMulti && mode == jRelight));
         if ((st | sh) == 0ULL || --rounds_left < 0) break;
 
@@ -203,6 +227,12 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
                     mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
                 }
             } else if (mode == jShade) {
+                // delta_t and the intersection_t the hit block reads (:586-618), rebuilt from the exit (kept out of the
+                // traversal loop's registers: delta_t = |1 / ray_dir| is |iv| bit for bit)
+                r.dtx = fabsf(ivx); r.dty = fabsf(ivy); r.dtz = fabsf(ivz);
+                r.itx = r.fmx ? t_exit + r.dtx : ((float)(r.sx > 0 ? r.vx + 1 : r.vx) - ox) * ivx;
+                r.ity = r.fmy ? t_exit + r.dty : ((float)(r.sy > 0 ? r.vy + 1 : r.vy) - oy) * ivy;
+                r.itz = r.fmz ? t_exit + r.dtz : ((float)(r.sz > 0 ? r.vz + 1 : r.vz) - oz) * ivz;
                 if (hit_block<kMulti>(r, mat, p)) {
                     mode = ended();
                 } else {
@@ -213,7 +243,6 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
             }
         }
     }
-    (void)t_exit;
 
     if (rounds_left < 0 && (tid & 63) == 0) {
         atomicAdd(&block_ctr[kCtrWatchdog], 1ULL);
