@@ -67,6 +67,11 @@ public:
     CLCaster &operator=(const CLCaster &) = delete;
 
     bool init(int device_ordinal = 0) { return ok(vrc_create(device_ordinal, &h_)); }                    // CLCaster.cpp:14-74
+    // the same object driving several GPUs from this one host thread: the frame is row-sliced over the devices, the
+    // scene replicated, compute() returns when every GPU is done, read_image*() gathers the slices (vrc_create_group)
+    bool init(const std::vector<int32_t> &device_ordinals, int band_rows = 8) {
+        return ok(vrc_create_group(device_ordinals.data(), (int32_t)device_ordinals.size(), band_rows, &h_));
+    }
 
     bool assign_map(const Map &m) {                                                                        // :76-87
         return ok(vrc_assign_map(h_, m.array_map.data(), (int32_t)m.dimensions, (int32_t)m.dimensions, (int32_t)m.dimensions));
