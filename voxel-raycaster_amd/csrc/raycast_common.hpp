@@ -22,6 +22,7 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 }
 
 struct Vec3 { float x, y, z; };
+constexpr unsigned kCountTex = 1u, kCountShadow = 0x100u, kCountBounce = 0x10000u;
 
 // OpenCL normalize(): v / |v|, v itself when it is all zero
 __device__ __forceinline__ Vec3 normalize3(Vec3 v) {
@@ -63,13 +64,12 @@ struct Ray {
     float itx, ity, itz;                 // intersection_t
     int fmx, fmy, fmz;                   // face_mask
     int distance_traveled, max_distance;
-    unsigned bounce_count;
-    float voxel_color[4], color_accumulator[4];
+    unsigned counts;                     // bits 0-7 atlas texels fetched, 8-15 shadow rays cast, 16-17 bounce_count
+    float voxel_color[3], color_accumulator[4];   // voxel_color.w is 0 from start to end in the reference (:684 "-= 0.0f")
     float fog_distance;
-    bool shadow_ray, written;
-    int flags;
-    int hit_vx, hit_vy, hit_vz, hit_mat, hit_face;
-    unsigned c_tex, c_shadow;
+    bool shadow_ray, written;            // (as bools they live in scalar masks; packed into `flags` they cost VGPRs)
+    int flags;                           // kFlag* bits 0-3, kFlagHasHit, face_mask of the primary hit in bits 8-10
+    long pix;                            // index of the pixel in the viewport / image / hit buffers
     // the first strike (primary hit): what the light block needs to run again for a further light
     int kvx, kvy, kvz;                   // the solid voxel
     float kfx, kfy, kfz;                 // face_position
@@ -82,12 +82,11 @@ struct Ray {
 // :276-323 + the frame-constant bias of :342-354.  Returns false for the
 // zero-component early return (:293-294): nothing is written for that pixel.
 __device__ __forceinline__ bool ray_setup(Ray &r, const RaycastParams &p, long pix) {
-    r.hit_vx = r.hit_vy = r.hit_vz = -1;
-    r.hit_mat = r.hit_face = r.flags = 0;
-    r.distance_traveled = 0;
-    r.bounce_count = 0;
+    r.pix = pix;
+    r.flags = 0;
     r.written = false;
-    r.c_tex = r.c_shadow = 0;
+    r.distance_traveled = 0;
+    r.counts = 0;
     r.light_index = 0;
 
     const float4 pm = reinterpret_cast<const float4 *>(p.viewport)[pix];
@@ -118,7 +117,8 @@ __device__ __forceinline__ bool ray_setup(Ray &r, const RaycastParams &p, long p
     r.max_distance = p.max_distance;                                          // :326
     r.fmx = r.fmy = r.fmz = 0;
 #pragma unroll
-    for (int c = 0; c < 4; c++) { r.voxel_color[c] = 0.0f; r.color_accumulator[c] = 0.0f; }
+    for (int c = 0; c < 4; c++) r.color_accumulator[c] = 0.0f;
+    r.voxel_color[0] = r.voxel_color[1] = r.voxel_color[2] = 0.0f;
     r.fog_distance = 0.0f;
     r.shadow_ray = false;
     r.written = true;
@@ -130,7 +130,8 @@ __device__ __forceinline__ void oob_exit(Ray &r) {
     r.vx -= r.sx * r.fmx; r.vy -= r.sy * r.fmy; r.vz -= r.sz * r.fmz;
     const float k = 1.0f - max_cl((float)r.distance_traveled / 700.0f, 0.0f);
 #pragma unroll
-    for (int c = 0; c < 4; c++) r.color_accumulator[c] = mix_cl(0.0f, r.voxel_color[c], k);
+    for (int c = 0; c < 3; c++) r.color_accumulator[c] = mix_cl(0.0f, r.voxel_color[c], k);
+    r.color_accumulator[3] = mix_cl(0.0f, 0.0f, k);
     r.color_accumulator[3] *= 4.0f;
     r.flags |= kFlagOob;
 }
@@ -153,7 +154,10 @@ __device__ __forceinline__ void restart_from(Ray &r, Vec3 hit_pos) {
 __device__ __forceinline__ bool light_from_strike(Ray &r, const RaycastParams &p, int l, bool cast) {
     const Vec3 light_pos{p.lights[l][4], p.lights[l][5], p.lights[l][6]};
     const Vec3 hit_pos{(float)r.kvx + r.kfx, (float)r.kvy + r.kfy, (float)r.kvz + r.kfz};
-    view_light(r.color_accumulator, l == 0 ? r.voxel_color : r.color_accumulator,
+    float in_color[4];
+    if (l == 0) { in_color[0] = r.voxel_color[0]; in_color[1] = r.voxel_color[1]; in_color[2] = r.voxel_color[2]; in_color[3] = 0.0f; }
+    else { in_color[0] = r.color_accumulator[0]; in_color[1] = r.color_accumulator[1]; in_color[2] = r.color_accumulator[2]; in_color[3] = r.color_accumulator[3]; }
+    view_light(r.color_accumulator, in_color,
                Vec3{hit_pos.x - light_pos.x, hit_pos.y - light_pos.y, hit_pos.z - light_pos.z}, p.lights[l],
                Vec3{hit_pos.x - p.cam_pos[0], hit_pos.y - p.cam_pos[1], hit_pos.z - p.cam_pos[2]}, r.kmx, r.kmy, r.kmz);
     if (!cast) return true;
@@ -164,7 +168,7 @@ __device__ __forceinline__ bool light_from_strike(Ray &r, const RaycastParams &p
     const Vec3 nd = normalize3(Vec3{light_pos.x - hit_pos.x, light_pos.y - hit_pos.y, light_pos.z - hit_pos.z});
     r.rdx = nd.x; r.rdy = nd.y; r.rdz = nd.z;                                 // :670
     if (r.rdx == 0.0f || r.rdy == 0.0f || r.rdz == 0.0f) { r.written = false; return false; }   // :671-672
-    r.c_shadow++;
+    r.counts += kCountShadow;
     r.flags |= kFlagShadowCast;
     r.vx = r.kvx - r.kmx; r.vy = r.kvy - r.kmy; r.vz = r.kvz - r.kmz;         // :674 voxel -= voxel_step * face_mask
     r.sx = isign(r.rdx); r.sy = isign(r.rdy); r.sz = isign(r.rdz);            // :675
@@ -217,9 +221,11 @@ __device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastP
     if (r.rdz > 0.0f) fpz = -fpz + 1.0f;
     if (r.rdz < 0.0f) tfy = -tfy + 1.0f;
 
-    if (r.hit_mat == 0 && !r.shadow_ray) {
-        r.hit_vx = r.vx; r.hit_vy = r.vy; r.hit_vz = r.vz; r.hit_mat = voxel_data;
-        r.hit_face = r.fmx | (r.fmy << 1) | (r.fmz << 2);
+    // the primary hit goes straight into the pixel's hit record (it would otherwise sit in five registers until the
+    // ray has finished); its face mask rides in the flags word
+    if (!(r.flags & kFlagHasHit) && !r.shadow_ray) {
+        if (p.hits) reinterpret_cast<int4 *>(p.hits)[2 * r.pix] = make_int4(r.vx, r.vy, r.vz, voxel_data);
+        r.flags |= kFlagHasHit | ((r.fmx | (r.fmy << 1) | (r.fmz << 2)) << 8);
     }
 
     if (r.shadow_ray) {                                                       // :707-710
@@ -235,7 +241,7 @@ __device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastP
     tx = tx < 0 ? 0 : (tx >= p.atlas_w ? p.atlas_w - 1 : tx);                 // undefined in OpenCL: clamp
     ty = ty < 0 ? 0 : (ty >= p.atlas_h ? p.atlas_h - 1 : ty);
     const uchar4 t8 = reinterpret_cast<const uchar4 *>(p.atlas)[(long)tx + (long)p.atlas_w * ty];
-    r.c_tex++;
+    r.counts += kCountTex;
     const float div = mirror ? 4.0f : 2.0f;
     r.voxel_color[0] += ((float)t8.x / 255.0f) / div;
     r.voxel_color[1] += ((float)t8.y / 255.0f) / div;
@@ -264,7 +270,7 @@ __device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastP
         r.sx = (-1 * (r.rdx > 0.0f ? -1 : 0)) - (r.rdx < 0.0f ? -1 : 0);
         r.sy = (-1 * (r.rdy > 0.0f ? -1 : 0)) - (r.rdy < 0.0f ? -1 : 0);
         r.sz = (-1 * (r.rdz > 0.0f ? -1 : 0)) - (r.rdz < 0.0f ? -1 : 0);
-        r.bounce_count += 1;
+        r.counts += kCountBounce;
     }
     restart_from(r, hit_pos);                                                 // :677-679 / :700-702
     r.hpx = hit_pos.x; r.hpy = hit_pos.y; r.hpz = hit_pos.z;
@@ -282,8 +288,8 @@ __device__ __forceinline__ void ray_finish(Ray &r, const RaycastParams &p, long 
     }
     if (!p.hits) return;
     int4 *hp = reinterpret_cast<int4 *>(p.hits) + 2 * pix;
-    hp[0] = make_int4(r.hit_vx, r.hit_vy, r.hit_vz, r.hit_mat);
-    hp[1] = make_int4(r.hit_face, r.flags | ((int)(r.bounce_count & 3) << 4), r.distance_traveled, (int)c_desc);
+    if (!(r.flags & kFlagHasHit)) hp[0] = make_int4(-1, -1, -1, 0);
+    hp[1] = make_int4((r.flags >> 8) & 7, (r.flags & 0xf) | ((int)((r.counts >> 16) & 3) << 4), r.distance_traveled, (int)c_desc);
 }
 
 // block id -> pixel.  Block b runs on XCD b % 8: xcd_mode 1 (default) deals the tile rows k, k+8, ... to XCD k when

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
                 } else {
                     restart_ray(r.hpx, r.hpy, r.hpz);
                     r.distance_traveled++;                    // :714
-                    mode = (r.distance_traveled < r.max_distance && r.bounce_count < 2) ? jStep : ended();
+                    mode = (r.distance_traveled < r.max_distance && (r.counts >> 16) < 2) ? jStep : ended();
                 }
             }
         }
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
     unsigned c_tex = 0, c_shadow = 0;
     if (in_image) {
         if (c_primary) {
-            c_tex = r.c_tex; c_shadow = r.c_shadow;
+            c_tex = r.counts & 0xffu; c_shadow = (r.counts >> 8) & 0xffu;
             if (!r.written) c_unwritten = 1;
         }
         ray_finish(r, p, pix, c_desc);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
             c_primary = 1;
             c_desc = (unsigned)p.frame[3];                // the reference's per-pixel get_oct_vox (:342)
             for (;;) {
-            while (r.distance_traveled < r.max_distance && r.bounce_count < 2) {          // :357
+            while (r.distance_traveled < r.max_distance && (r.counts >> 16) < 2) {          // :357
                 c_steps++;
                 r.fmx = r.itx <= min_cl(r.ity, r.itz);                                      // :558
                 r.fmy = r.ity <= min_cl(r.itz, r.itx);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
                 r.distance_traveled = r.kdist + 1;        // as if the strike iteration had just finished (:714)
             }
             if (!r.written) c_unwritten = 1;
-            c_tex = r.c_tex; c_shadow = r.c_shadow;
+            c_tex = r.counts & 0xffu; c_shadow = (r.counts >> 8) & 0xffu;
         }
         ray_finish(r, p, pix, c_desc);
     }
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
                     t_unsafe = true;
                     if (kJump) jump_cache_reset(jcache);  // delta_t changed with the redirect
                     r.distance_traveled++;                // :714
-                    mode = (r.distance_traveled < r.max_distance && r.bounce_count < 2) ? kStep : ended();   // :357
+                    mode = (r.distance_traveled < r.max_distance && (r.counts >> 16) < 2) ? kStep : ended();   // :357
                 }
             }
         }
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
     if (in_image) {
         if (c_primary) {
             c_steps = (unsigned)(steps_base + r.distance_traveled) + broke;
-            c_tex = r.c_tex; c_shadow = r.c_shadow;
+            c_tex = r.counts & 0xffu; c_shadow = (r.counts >> 8) & 0xffu;
             if (!r.written) c_unwritten = 1;
         }
         ray_finish(r, p, pix, c_desc);

@@ -26,6 +26,7 @@ constexpr int kMaxLevels = 24;        // descriptor levels the LDS stack can hol
 
 // hit-record flag bits (include/vrc.h VRC_HIT_FLAG_*)
 constexpr int kFlagWritten = 1, kFlagShadowCast = 2, kFlagShadowHit = 4, kFlagOob = 8;
+constexpr int kFlagHasHit = 0x800;     // internal: the primary hit has been recorded (bits above 7 never leave the kernels)
 
 // counters[] slots (device, uint64)
 enum CounterSlot {
