@@ -13,22 +13,27 @@
  * load this library, and only as the checker.  The product (libvrc.so) never
  * links or calls it.
  *
- * PARTLY PINNED.  get_oct_vox (a3) and view_light (the shading arithmetic of a6) are pinned against the
- * reference's own code: kernels/ray_caster_kernel.cl compiles unmodified for gfx950, oracle/ref_probe.cl includes it
- * from /root/reference and calls the two functions from probe kernels, and tests/test_reference_pin_gpu.py
- * compares them with this file on the MI355X (get_oct_vox: every field equal; view_light: 99.98 % of cases within
- * 1e-5 relative, worst 3.1e-5 -- the OpenCL library's normalize/fast_length are approximate).
- * PARITY UNPINNED for the rest (a2 builder, a4 ray table, a5 step loop, UV/texel/redirect code of a6, a7): the
- * reference ships no tests, golden vectors or fixtures, its host code (Octree.cpp, CLCaster.cpp,
- * Ray.cpp) needs SFML/OpenCL/GL headers and libraries the image lacks (writing stand-ins is not allowed), and its
- * raycaster kernel has no observable output on an MI355X because CDNA4 has no image hardware:
- * read_imagef/write_imagef lower to no-ops and the AMD OpenCL runtime refuses clCreateImage
- * (CL_INVALID_OPERATION); evidence in profiles/r01_reference_kernel_on_gfx950.txt.  Those parts are a
- * line-by-line restatement (each block cites the reference line it follows) checked by (a) the reference's own
- * self-check Octree::Validate (src/map/Octree.cpp:329-352), (b) a second, independently written builder in the
- * product (bit-identical output), (c) Ray::Cast's constant known answer, (d) array-branch == SVO-occupancy
- * equality on the same grid.  tests/golden/orc_*.npz are regression vectors produced by THIS oracle, not by the
- * reference.  See DESIGN.md "Oracle and pinning".
+ * PINNING STATUS.  Pinned against the reference's own compiled code: get_oct_vox (a3) and view_light (the shading
+ * arithmetic of a6) -- kernels/ray_caster_kernel.cl compiles unmodified for gfx950, oracle/ref_probe.cl includes it
+ * from /root/reference and calls the two functions from probe kernels, tests/test_reference_pin_gpu.py compares them
+ * with this file on the MI355X (get_oct_vox: every field equal; view_light: 99.98 % of cases within 1e-5 relative,
+ * worst 3.1e-5 -- the OpenCL library's normalize/fast_length are approximate).
+ * Checked against outputs of the reference's WHOLE raycaster kernel (a4 device part, a5, a6, epilogue): the kernel is
+ * run on the MI355X with its two image builtins (write_imagef / read_imagef -- CDNA4 has no image hardware, they lower
+ * to nothing: profiles/r01_reference_kernel_on_gfx950.txt) redirected by macro to stores of the kernel's own locals
+ * (oracle/ref_raycaster_probe.cl); live in tests/test_reference_pin_gpu.py and, as committed vectors
+ * tests/golden/ref_*.npz (generator tests/make_reference_golden.py), in tests/test_oracle_cpu.py.  Hit voxel, face,
+ * material, texel fetches, bounce count, written/unwritten pixels, step count and colour of rays that hit nothing:
+ * equal on every pixel of 8 scenes; final step count, shadow flag, RGB (1e-5) of shaded pixels: equal on 100 %.
+ * Because two I/O builtins are overridden this counts as corroboration, not as a pin in the strict sense.
+ * UNPINNED: the a2 builder, the host part of a4 (ray table) and a7 -- the reference ships no tests, golden vectors or
+ * fixtures and its host code (Octree.cpp, CLCaster.cpp, Ray.cpp) needs SFML/OpenCL/GL headers and
+ * libraries the image lacks (writing stand-ins is not allowed).  Those parts are a line-by-line restatement (each
+ * block cites the reference line it follows) checked by (a) the reference's own self-check Octree::Validate
+ * (src/map/Octree.cpp:329-352), (b) a second, independently written builder in the product (bit-identical output),
+ * (c) Ray::Cast's constant known answer, (d) the reference kernel above accepting the oracle-built tree and table.
+ * tests/golden/orc_*.npz are regression vectors produced by THIS oracle, not by the reference.
+ * See DESIGN.md "Oracle and pinning".
  *
  * Float semantics: IEEE-754 binary32, no contraction (build with
  * -ffp-contract=off), correctly rounded / and sqrt.  sin/cos of the camera

@@ -385,3 +385,24 @@ def test_oracle_reproduces_committed_vectors(path):
     assert np.array_equal(img.view(np.uint32), g["image"].view(np.uint32))
     assert np.array_equal(hits, g["hits"])
     assert ctr == g["counters"]
+
+
+# ---------------------------------------------------------------- reference-produced vectors
+REF_GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ref_*.npz")))
+
+
+@pytest.mark.skipif(not REF_GOLDEN, reason="tests/golden/ref_*.npz missing (tests/make_reference_golden.py, GPU box)")
+@pytest.mark.parametrize("path", REF_GOLDEN, ids=[os.path.basename(p) for p in REF_GOLDEN])
+def test_oracle_matches_the_reference_kernel_vectors(path, atlas):
+    """tests/golden/ref_*.npz are outputs of the REFERENCE'S OWN raycaster kernel run on an MI355X (generator:
+    tests/make_reference_golden.py; the kernel's two image builtins are redirected to buffers).
+    The oracle must reproduce them: written / unwritten pixels, hit voxel, face, material, texel fetches, bounce count,
+    step count and colour of rays that hit nothing exactly; final step count, shadow flag and RGB (1e-5) of shaded
+    pixels on >= 99.5 % (the reference's normalize / fast_distance are the OpenCL library's approximations)."""
+    import refcompare
+    z = np.load(path)
+    s = getattr(scenes, str(z["scene"]))()
+    w, h = int(z["width"]), int(z["height"])
+    buf, root = orc.octree_generate(s["grid"], s["dim"])
+    oimg, ohits, octr = refcompare.oracle_frame(s, w, h, atlas, buf, root, z["trig"], threads=4)
+    refcompare.compare(s, w, h, z["records"], oimg, ohits, octr, verbose=False)

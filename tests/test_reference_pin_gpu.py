@@ -118,6 +118,7 @@ def test_get_oct_vox_of_the_oracle_matches_the_reference_function(probe, dim, de
 # step loop (:555-570), hit block (:575-711) and epilogue (:716-721) rather than pinning them in the strict sense --
 # but a misreading of an OpenCL-C quirk shared by the oracle and the HIP kernels (vector compare = -1, comma
 # "literals", select's MSB rule, the :698 precedence) would show up here as a different hit voxel or step count.
+import refcompare  # noqa: E402
 import scenes  # noqa: E402
 
 REC_WORDS = 32
@@ -162,41 +163,8 @@ def test_reference_raycaster_step_loop_against_the_oracle(probe, make, res, atla
         pytest.skip("oracle/_ref/ref_raycaster_gfx950_strict.co not built (make -C oracle _ref)")
     s, (w, h) = make(), res
     rec, trig, buf, root = run_reference_raycaster(probe, "ref_raycaster_gfx950_strict.co", s, w, h, atlas)
-    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=s["lights"], atlas=atlas,
-                                    tile_dim=(16, 16), descriptors=buf, root_index=root, octree_dim=s["dim"], using_octree=1,
-                                    grid=s["grid"], max_distance=20, trig=trig, threads=8)
-    written = rec[..., 15] == 1
-    # pixels the kernel returned from without writing (:293-294, :671-672, :694-695)
-    assert np.array_equal(written, (ohits[..., 5] & 1) == 1), "written / unwritten pixels differ"
-    assert octr["unwritten"] == int((~written).sum())
-    # the first solid hit of the primary ray: recorded at the kernel's first read_imagef (:652 / :684)
-    hit = rec[..., 16] > 0
-    assert np.array_equal(hit, ohits[..., 3] != 0), "which pixels hit something differs"
-    assert np.array_equal(rec[..., 17:20][hit], ohits[..., 0:3][hit]), "hit voxel"
-    face = rec[..., 20] | (rec[..., 21] << 1) | (rec[..., 22] << 2)
-    assert np.array_equal(face[hit], ohits[..., 4][hit]), "hit face"
-    assert np.array_equal(rec[..., 23][hit], ohits[..., 3][hit]), "hit material"
-    assert octr["n_tex"] == int(rec[..., 16].sum()), "texel fetches"
-    # rays that never hit anything: the whole ray is primary, so the end state is exact too
-    miss = written & ~hit
-    assert np.array_equal(rec[..., 11][miss], ohits[..., 6][miss]), "step count of rays that hit nothing"
-    fcol = rec[..., 0:4].view(np.float32)
-    assert np.array_equal(fcol[miss].view(np.uint32), oimg[miss].view(np.uint32)), "colour of rays that hit nothing"
-    # mirror bounces (:682-704)
-    assert np.array_equal(rec[..., 13][written], (ohits[..., 5][written] >> 4) & 3), "bounce count"
-    # after the shadow redirect: library normalize / fast_distance -> statistics, near-total agreement required
-    w_ = written & hit
-    if w_.any():
-        same_steps = rec[..., 11][w_] == ohits[..., 6][w_]
-        rel = np.abs(fcol[w_][:, :3] - oimg[w_][:, :3]) / np.maximum(np.abs(oimg[w_][:, :3]), 1e-6)
-        shadow_same = (rec[..., 12][w_] != 0) == ((ohits[..., 5][w_] & 2) != 0)
-        alpha_same = (np.abs(fcol[w_][:, 3] - oimg[w_][:, 3]) <= 1e-5 * np.maximum(np.abs(oimg[w_][:, 3]), 1e-6))
-        print(f"\n{s['name']} {w}x{h}: {int(w_.sum())} shaded pixels; final step count equal {same_steps.mean():.5f}, "
-              f"rgb within 1e-5 {float((rel.max(-1) <= 1e-5).mean()):.5f} (worst {float(rel.max()):.2e}), "
-              f"alpha (in-shadow flag) equal {alpha_same.mean():.5f}")
-        assert shadow_same.all()
-        assert same_steps.mean() >= 0.995 and alpha_same.mean() >= 0.995
-        assert (rel.max(-1) <= 1e-4).mean() >= 0.995
+    oimg, ohits, octr = refcompare.oracle_frame(s, w, h, atlas, buf, root, trig)
+    refcompare.compare(s, w, h, rec, oimg, ohits, octr)
 
 
 def test_reference_raycaster_with_the_references_own_flags(probe, atlas):
