@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Long-running parity soak (not collected by pytest): random camera poses / lights / step caps in the depth-12 bench
-scene and random small scenes, GPU vs oracle, bit for bit.  python tests/soak_gpu.py [seconds] [seed] [depth]"""
+scene, GPU vs oracle, bit for bit, in both stepping modes (the exact kernel against the reference restatement, the
+node-exit jump kernel against its own restatement), with hit records, row slices of a 3-rank group handle and the
+device-side RGBA8 pack in the loop.  python tests/soak_gpu.py [seconds] [seed] [depth]"""
 import os
 import sys
 import time
@@ -21,7 +23,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     sc = bench.build_scene(int(sys.argv[3]) if len(sys.argv) > 3 else 12)
     dim, w, h = sc["dim"], 512, 288
-    t0, poses, rows, bad = time.time(), 0, 0, 0
+    t0, poses, rows, bad, by_mode = time.time(), 0, 0, 0, [0, 0]
     while time.time() - t0 < budget:
         cam_pos = tuple(float(v) for v in (rng.random(3) * (dim * 1.2) - 0.1 * dim))
         if rng.random() < 0.5:                       # mostly above the terrain
@@ -32,23 +34,42 @@ def main():
         lights = sc["lights"].copy()
         lights[:, 4:7] = rng.random((8, 3)) * dim * 1.1
         md = int(rng.choice([3 * dim, 3 * dim, 700, 5000]))
-        c = make_caster(sc["octree"], dim, 0, cam_dir, cam_pos, lights, sc["atlas"], w, h, md, light_count=nl)
+        mode = int(rng.integers(0, 2))
+        grouped = rng.random() < 0.25
+        if grouped:                                  # three ranks on GPU 0 behind one handle: row slices, gathered read-back
+            c = vrc.CLCaster()
+            assert c.init_group([0, 0, 0], band_rows=8)
+            cd, cp = np.array(cam_dir, dtype=np.float32), np.array(cam_pos, dtype=np.float32)
+            ok = (c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c.add_to_settings_buffer("using_octree", "OCTENABLED", 0)
+                  and c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", md) and c.add_to_settings_buffer("light_count", "LIGHT_COUNT", nl)
+                  and c.assign_octree(sc["octree"]) and c.assign_camera(cd, cp) and c.create_viewport(w, h) and c.assign_lights(lights)
+                  and c.create_texture_atlas(sc["atlas"], (16, 16)) and c.validate())
+            assert ok, c.last_error()
+            c._li = lights
+        else:
+            c = make_caster(sc["octree"], dim, 0, cam_dir, cam_pos, lights, sc["atlas"], w, h, md, light_count=nl)
+        assert c.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", mode)
         assert c.compute(), c.last_error()
-        img, hits = c.read_image(), c.read_hits()
+        img, hits, rgba = c.read_image(), c.read_hits(), c.read_image_rgba8()
+        if not np.array_equal(rgba, orc.image_to_rgba8(img)):
+            bad += 1
+            print("RGBA8 MISMATCH", cam_pos, cam_dir, flush=True)
         for y0 in rng.choice(h // 8, size=3, replace=False) * 8:
             oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=sc["atlas"],
                                          tile_dim=(16, 16), descriptors=sc["octree"].descriptor_buffer,
                                          root_index=sc["octree"].root_index, octree_dim=dim, using_octree=0, max_distance=md,
-                                         rows=(int(y0), int(y0) + 8), threads=16, active_lights=nl)
+                                         rows=(int(y0), int(y0) + 8), threads=16, active_lights=nl, stepping_mode=mode)
             same = np.array_equal(hits[y0:y0 + 8], ohits[y0:y0 + 8]) and \
                 np.array_equal(img[y0:y0 + 8].view(np.uint32), oimg[y0:y0 + 8].view(np.uint32))
             rows += 8
             if not same:
                 bad += 1
-                print("MISMATCH", cam_pos, cam_dir, nl, md, int(y0), flush=True)
+                print("MISMATCH", "mode", mode, "grouped", grouped, cam_pos, cam_dir, nl, md, int(y0), flush=True)
         poses += 1
+        by_mode[mode] += 1
         del c
-    print(f"soak: {poses} poses, {rows} rows of {w} pixels compared, {bad} mismatching bands, {time.time() - t0:.0f} s")
+    print(f"soak: {poses} poses ({by_mode[0]} exact, {by_mode[1]} mode B), {rows} rows of {w} pixels compared, {bad} mismatching bands, "
+          f"{time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 
