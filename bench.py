@@ -310,7 +310,7 @@ def main():
         bytes_per_launch = algorithmic_bytes(ctr, local_pixels, written)
         avg_kernel_s = kernel_ms / max(n_launch, 1) / 1e3
         achieved = bytes_per_launch / avg_kernel_s / 1e9
-        # HBM bytes and VALU instructions per launch come from rocprofv3 PMC passes (tools/gpu_pmc.sh: counters cannot be
+        # HBM bytes and VALU instructions per launch come from rocprofv3 PMC passes (tools/gpu_profile.sh: counters cannot be
         # read inside this process).  The committed measurement is stamped with the hash of the kernel sources it was
         # taken on; a different kernel => null, never a stale number.
         traffic, issue, pmc_note = None, None, "no PMC measurement for this workload"
@@ -329,7 +329,7 @@ def main():
                              "achieved_ginst_s": round(rate, 1), "peak_ginst_s": VALU_PEAK_GINST_S,
                              "frac": round(rate / VALU_PEAK_GINST_S, 4)}
             else:
-                pmc_note = "profiles/traffic_latest.json was measured on other kernel sources: re-run tools/gpu_bench_profile.sh"
+                pmc_note = "profiles/traffic_latest.json was measured on other kernel sources: re-run tools/gpu_profile.sh + tools/update_profiles.py"
         out = {
             "metric": "Mrays/s (primary+shadow), 1920x1080 into depth-12 SVO",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
