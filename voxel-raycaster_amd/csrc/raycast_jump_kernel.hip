@@ -32,6 +32,16 @@ enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4 };
 // 5 / 6 / 7 blocks: 0.93 / 0.91 / 0.85 ms on the headline frame; the kernel waits on dependent loads half of the time
 // (profiles/r02_pmc_mode_b.txt), so residency beats spill-free registers.  LDS (22.5 KB of stack per block at depth 12)
 // allows 7 blocks per CU as well.
+// scheduling of the two blocks of a round (see the main loop); results never depend on it.  Measured on the headline
+// frame: both blocks every round 0.869 ms; jump block only when n_jump >= n_descend / 2 / 0.75 n_descend / n_descend:
+// 0.88 / 0.87 / 0.86 ms; the same votes without the descent block after a jump: 1.00 ms -- so the default stays "both".
+#ifndef VRC_JUMP_VOTE_NUM
+#define VRC_JUMP_VOTE_NUM 0          // 0: the jump block runs whenever a lane waits for it
+#define VRC_JUMP_VOTE_DEN 1
+#endif
+#ifndef VRC_DESCEND_AFTER_JUMP
+#define VRC_DESCEND_AFTER_JUMP 1     // 1: a round that jumped also runs the descent block
+#endif
 #ifndef VRC_JUMP_MIN_BLOCKS
 #define VRC_JUMP_MIN_BLOCKS (28 / VRC_TILES_PER_BLOCK)
 #endif
@@ -51,7 +61,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
 
     Ray r;
     unsigned c_primary = 0, c_desc = 0, c_unwritten = 0, c_steps = 0;
-    int mode = jDone, mat = 5;
+    int mode = jDone;
     auto ended = [&]() -> int { return (kMulti && more_lights(r, p)) ? jRelight : jDone; };
 
     // the ray as a line: origin + t * ray_dir, and the empty node [corner, corner + size)^3 the voxel is in
@@ -61,7 +71,14 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
 
     const int n = p.log2_dim;
     const uint64_t *__restrict__ descriptors = p.descriptors;
-    uint64_t root_entry = 0, cur = 0;
+    // the root's entry is the same for every ray of the frame: it lives in scalar registers
+    uint64_t root_entry;
+    {
+        const uint64_t e = jump_make_entry(descriptors, p.root_index, descriptors[p.root_index]);
+        root_entry = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(e >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)e);
+    }
+    uint64_t cur = 0;
     int top = 0, pvx = 0, pvy = 0, pvz = 0;
 
     // returns b >= 0: voxel lies in an empty node of size 2^b;  -1: voxel is solid   (canonical traversal)
@@ -120,9 +137,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
         } else {
             // ray_setup added the octree bias of :353-354 to intersection_t; this mode never reads intersection_t
             c_primary = 1;
-            const uint64_t d = descriptors[p.root_index];
-            c_desc = 1;
-            root_entry = jump_make_entry(descriptors, p.root_index, d);
+            c_desc = 1;                                   // the root read of this ray (canonical count)
             cur = root_entry;
             int b = -1;
             if (r.vx >= 0 && r.vy >= 0 && r.vz >= 0 && r.vx < p.map_dim[0] && r.vy < p.map_dim[1] && r.vz < p.map_dim[2])
@@ -135,11 +150,23 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
 
     const int shade_threshold = kDefaultShadeThreshold;
     int rounds_left = p.watchdog_rounds;
+#ifdef VRC_SCHED_STATS
+    // profiling build only: lane-rounds by what the lane was doing when the round started
+    unsigned s_rounds = 0, s_step = 0, s_descend = 0, s_parked = 0, s_done = 0, s_shade_passes = 0;
+#endif
     for (;;) {
-        // One round = every live lane takes ONE step of its own chain: a node-exit jump (pure arithmetic + the pop to the
-        // common ancestor, an LDS read) and/or one level of the descent toward the voxel it landed in (one dependent 8-byte
-        // load).  Lanes do not wait for each other's descents: a wave needs as many rounds as its longest lane has loads,
-        // not the sum over events of the deepest descent among its lanes.
+#ifdef VRC_SCHED_STATS
+        if ((tid & 63) == 0) s_rounds++;
+        s_step += mode == jStep; s_descend += mode == jDescend; s_parked += (mode == jShade || mode == jRelight); s_done += mode == jDone;
+#endif
+        // One round = one block of code for the lanes that wait for it: the node-exit JUMP (pure arithmetic + the pop to
+        // the common ancestor, an LDS read) or one level of the DESCENT toward the voxel a lane landed in (one dependent
+        // 8-byte load).  A jump is followed by ~2 descent steps on average, so running both blocks every round leaves the
+        // jump block 38 % full (tools/mode_b_stats.py); the wave votes instead: the jump block runs when at least
+        // VRC_JUMP_VOTE_NUM / VRC_JUMP_VOTE_DEN as many lanes wait to jump as wait to descend.
+        const int n_jump = __popcll(__ballot(mode == jStep)), n_desc = __popcll(__ballot(mode == jDescend));
+        const bool do_jump = n_jump > 0 && (n_desc == 0 || n_jump * VRC_JUMP_VOTE_DEN >= n_desc * VRC_JUMP_VOTE_NUM);
+        if (do_jump)
         if (mode == jStep) {
             const float plx = (float)(r.sx > 0 ? cx + size : cx), ply = (float)(r.sy > 0 ? cy + size : cy),
                         plz = (float)(r.sz > 0 ? cz + size : cz);
@@ -182,7 +209,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
                 }
             }
         }
-        if (mode == jDescend) {
+        if ((!do_jump || VRC_DESCEND_AFTER_JUMP) && mode == jDescend) {
             const int b = n - top - 1;
             const int i = ((r.vx >> b) & 1) | (((r.vy >> b) & 1) << 1) | (((r.vz >> b) & 1) << 2);
             const unsigned masks = (unsigned)cur & 0xffffu;
@@ -193,9 +220,9 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
                 mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
             } else if (((masks >> 8) & bit) || b == 0) {      // solid
                 set_node(1);
-                mat = solid_material(r.vx, r.vy, r.vz);
-                if (mat == 5 || mat == 6) {                   // :575
-                    mode = jShade;                            // the hit block is deferred
+                const int m5 = solid_material(r.vx, r.vy, r.vz);
+                if (m5 == 5 || m5 == 6) {                     // :575
+                    mode = jShade;                            // the hit block is deferred (the material is looked up again there)
                 } else {                                      // any other material is passed through
                     r.distance_traveled++;
                     mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
@@ -215,6 +242,9 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
 
         // ---- hit block (:575-711): runs when many lanes wait for it or nothing cheaper is left
         if (sh != 0ULL && (st == 0ULL || __popcll(sh) >= shade_threshold)) {
+#ifdef VRC_SCHED_STATS
+            if ((tid & 63) == 0) s_shade_passes++;
+#endif
             if (kMulti && mode == jRelight) {                 // back to the first strike for the next light
                 r.light_index++;
                 if (!light_from_strike(r, p, r.light_index, true)) {
@@ -233,7 +263,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
                 r.itx = r.fmx ? t_exit + r.dtx : ((float)(r.sx > 0 ? r.vx + 1 : r.vx) - ox) * ivx;
                 r.ity = r.fmy ? t_exit + r.dty : ((float)(r.sy > 0 ? r.vy + 1 : r.vy) - oy) * ivy;
                 r.itz = r.fmz ? t_exit + r.dtz : ((float)(r.sz > 0 ? r.vz + 1 : r.vz) - oz) * ivz;
-                if (hit_block<kMulti>(r, mat, p)) {
+                if (hit_block<kMulti>(r, solid_material(r.vx, r.vy, r.vz), p)) {
                     mode = ended();
                 } else {
                     restart_ray(r.hpx, r.hpy, r.hpz);
@@ -256,6 +286,14 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
         }
         ray_finish(r, p, pix, c_desc);
     }
+#ifdef VRC_SCHED_STATS
+    atomicAdd(&block_ctr[kCtrWaveIters], (unsigned long long)s_rounds);
+    atomicAdd(&block_ctr[kCtrBursts], (unsigned long long)s_step);
+    atomicAdd(&block_ctr[kCtrEventPasses], (unsigned long long)s_descend);
+    atomicAdd(&block_ctr[kCtrEventLanes], (unsigned long long)s_parked);
+    atomicAdd(&block_ctr[kCtrShadePasses], (unsigned long long)s_shade_passes);
+    atomicAdd(&block_ctr[kCtrShadeLanes], (unsigned long long)s_done);
+#endif
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
     publish_counters(p, block_ctr, vals);
 }
