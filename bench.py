@@ -7,7 +7,8 @@
 
 A "step" is one vrc_compute(): one pass of the raycast kernel over this rank's rows of the frame,
 synchronous like the reference's compute() (src/CLCaster.cpp:224-228, clFinish :970).  All inputs
-(SVO, ray table, atlas) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+(SVO, ray table, atlas) are resident in HBM before the timed region; the frame is the production frame (the image and
+nothing else, like the reference: setting hit_records = 0).  Prints ONE JSON line on rank 0.
 
 N = 1: BASELINE.json configs[2] -- 4096^3 shell-terrain SVO (seed 1), 1920x1080, primary rays +
 one shadow ray per hit + Blinn-Phong + atlas, the reference's own ray table.
