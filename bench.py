@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PREWARM_FRAMES = 40     # untimed frames rendered during set-up so that the GPU clocks have settled before the W warm-up steps
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 # VALU issue peak: 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles per SIMD, 2.4 GHz (MI355X_MICROARCH.md)
 VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
@@ -281,6 +282,11 @@ def main():
         if rank == 0:
             os.remove(tree_file)
 
+    # set-up, not measurement: a fresh process finds the GPU at its idle clocks, and a 3 ms kernel needs a few dozen
+    # launches before DVFS settles (measured: the first timed block of a run is 2-3 % slower than the second)
+    for _ in range(PREWARM_FRAMES):
+        if not c.compute():
+            raise SystemExit("compute failed: " + c.last_error())
     for _ in range(args.warmup):
         if not c.compute():
             raise SystemExit("compute failed: " + c.last_error())
@@ -342,6 +348,7 @@ def main():
                        "descriptors": int(sc["octree"].descriptor_buffer.size),
                        "rays_per_step": int(total_rays), "parallelism": f"row-slices x{world}, SVO replicated",
                        "stepping": "exact per-voxel DDA (bit-identical to the reference array branch)",
+                       "prewarm_frames": PREWARM_FRAMES,
                        "frame": "production frame: image only, like the reference (hit_records = 0); with_hit_records is the same frame plus the parity records"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
