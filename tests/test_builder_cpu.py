@@ -66,3 +66,18 @@ def test_oracle_paged_descriptor_source_equals_the_flat_array(atlas):
     img_b, hits_b, ctr_b = orc.raycast(descriptors=paged, threads=4, **kw)
     assert np.array_equal(img_a.view(np.uint32), img_b.view(np.uint32)) and np.array_equal(hits_a, hits_b) and ctr_a == ctr_b
     assert len(reads) == len(set(reads)) and 0 < paged.bytes_fetched <= (desc.size + orc.PAGE_SIZE) * 8
+
+
+def test_host_builders_under_sanitizers(tmp_path):
+    """csrc/svo_builder.cpp (builders, scene functions, file format) compiled with g++ -fsanitize=address,undefined and
+    driven through the C ABI: no report, no leak (GPU sanitizers are not available on the pool; this is the host side)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_sanitize")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "host_sanitize.cpp"),
+                           os.path.join(root, "voxel-raycaster_amd", "csrc", "svo_builder.cpp"), "-o", exe])
+    out = subprocess.run([exe, str(tmp_path / "t.svo")], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0 and "host sanitize ok" in out.stdout, out.stdout + out.stderr
