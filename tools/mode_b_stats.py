@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Lane-round statistics of the mode-B kernel on the headline frame: what the lanes of a wave are doing when a round
+starts.  Needs a profiling build of the library: bash tools/build_variant.sh stats -DVRC_SCHED_STATS, copied over
+voxel-raycaster_amd/libvrc.so on the GPU box (tools/gpu_variants.sh does the copying)."""
 import sys, os, json
 sys.path.insert(0, '/root/repo')
 import bench
