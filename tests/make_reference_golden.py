@@ -26,6 +26,7 @@ import scenes  # noqa: E402
 import test_reference_pin_gpu as pin  # noqa: E402
 
 RESOLUTIONS = {"64x48": (64, 48), "256x192": (256, 192)}
+EXTRA = {"terrain256": {"640x480": (640, 480)}}      # one wide frame of the natural scene
 
 
 def main(out_dir):
@@ -34,7 +35,7 @@ def main(out_dir):
     lib.ref_probe_last_error.restype = C.c_char_p
     atlas = scenes.hash_atlas()
     for make in scenes.REFERENCE_KERNEL_SCENES:
-        for tag, (w, h) in RESOLUTIONS.items():
+        for tag, (w, h) in {**RESOLUTIONS, **EXTRA.get(make.__name__, {})}.items():
             s = make()
             rec, trig, _, _ = pin.run_reference_raycaster(lib, "ref_raycaster_gfx950_strict.co", s, w, h, atlas)
             path = os.path.join(out_dir, f"ref_{make.__name__}_{tag}.npz")

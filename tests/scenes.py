@@ -119,6 +119,18 @@ def near_mirror(dim=32):
     return s
 
 
+def terrain256():
+    """The 256^3 shell terrain (BASELINE configs[0] geometry: 67 689 descriptors, inside the reference's 100 000-entry
+    buffer and its 8-level kernel stacks) seen from 3 voxels above the ground, looking 40 degrees down: slopes, x / z
+    faces, lit and shadowed ground within the reference kernel's 20 steps."""
+    import voxel_raycaster_amd as vrc
+    dim, cx, cy = 256, 128, 40
+    grid = vrc.shell_terrain_dense(8, seed=1, thickness=2)
+    lo, hi = vrc.shell_column(8, cx, cy, seed=1, thickness=2)
+    lights = np.array([[0.01, 0.01, 0.01, 0.2, 64.0, 64.0, 192.0, -1, -1, -1.5]], dtype=np.float32)
+    return dict(name="terrain256", dim=dim, grid=grid, cam_pos=(cx + 0.37, cy + 0.41, hi + 3.3), cam_dir=(2.3, 1.5708), lights=lights)
+
+
 ALL = [app_default, floor_pillars, mirror_wall, open_sky, axis_aligned, random_sparse]
 # the scenes the reference's own kernel is run on (tests/test_reference_pin_gpu.py): its step cap is 20
-REFERENCE_KERNEL_SCENES = ALL + [shadow_box, near_mirror]
+REFERENCE_KERNEL_SCENES = ALL + [shadow_box, near_mirror, terrain256]
