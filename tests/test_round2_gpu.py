@@ -248,6 +248,26 @@ def test_group_handle_is_one_synchronous_compute_over_all_ranks(ranks, atlas):
     assert g.octree_size()[0] == info["n_descriptors"] and g.counters()["primary_rays"] == w * h
 
 
+def test_group_with_more_ranks_than_row_bands(atlas):
+    """A 20-row frame on 4 ranks in bands of 8: ranks 0-2 own 8, 8 and 4 rows, rank 3 owns none -- still one frame."""
+    s = scenes.floor_pillars()
+    dim, w, h = s["dim"], 96, 20
+    m = vrc.Map(dim, s["grid"])
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = s["lights"]
+    one = vrc.CLCaster()
+    assert one.init(0) and one.assign_octree(m.octree)
+    configure(one, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
+    assert one.validate() and one.compute()
+    g = vrc.CLCaster()
+    assert g.init_group([0, 0, 0, 0]) and g.assign_octree(m.octree)
+    configure(g, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
+    assert g.validate() and g.compute(), g.last_error()
+    assert [g.memory_usage(r)["rows"] for r in range(4)] == [8, 8, 4, 0]
+    assert np.array_equal(g.read_image().view(np.uint32), one.read_image().view(np.uint32))
+    assert np.array_equal(g.read_hits(), one.read_hits()) and g.counters() == one.counters()
+
+
 # ------------------------------------------------------------------ streamed upload vs the ORACLE
 @pytest.mark.parametrize("depth,chunk", [(10, 1 << 20), (12, 64 << 20), (13, 64 << 20)], ids=["d10-1MB-chunks", "d12-3-chunks", "d13-11-chunks"])
 def test_streamed_upload_multi_chunk_against_the_oracle(depth, chunk, tmp_path):

@@ -66,6 +66,7 @@ struct vrc_caster {
     int32_t tile_rank = 0, tile_world = 1, band_rows = 8;
     bool validated = false;
     int last_blocks = 0;
+    uint64_t frames_enqueued = 0;
     uint64_t sched_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // kernel timing
@@ -828,6 +829,7 @@ int compute_async_one(vrc_caster *h) {
     }
     p.counters = h->d_partials;
     h->last_blocks = nblocks;
+    h->frames_enqueued++;
 
     vrc_caster::EvPair ev;
     if (!h->pool.empty()) { ev = h->pool.back(); h->pool.pop_back(); }
@@ -962,6 +964,10 @@ int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out) {
 
 namespace {
 int counters_one(vrc_caster *h, unsigned long long c[vrc::kCtrCount]) {
+    if (h->frames_enqueued && h->last_blocks == 0) {             // a rank that owns no rows of this frame (more ranks than bands)
+        memset(c, 0, sizeof(unsigned long long) * vrc::kCtrCount);
+        return VRC_OK;
+    }
     if (!h->d_partials || h->last_blocks <= 0) return fail(h, VRC_ERR_NOT_READY, "get_counters: no frame computed");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, vrc::launch_reduce_counters(h->d_partials, h->last_blocks, h->d_counters, h->stream));
