@@ -36,7 +36,7 @@ PREWARM_FRAMES = 40     # untimed frames rendered during set-up so that the GPU 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 # VALU issue peak: 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles per SIMD, 2.4 GHz (MI355X_MICROARCH.md)
 VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
-KERNEL_SOURCES = ("raycast_kernel.hip", "raycast_common.hpp", "safe_run.hpp", "exact_jump.hpp", "vrc_params.h")
+KERNEL_SOURCES = ("raycast_kernel.hip", "raycast_jump_kernel.hip", "raycast_common.hpp", "safe_run.hpp", "exact_jump.hpp", "vrc_params.h")
 
 
 def kernel_source_hash() -> str:

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
 
         // ---- phase 4: hit block (:575-711): expensive and needed ~twice per pixel, so it runs only when
         // many lanes wait for it or nothing cheaper is left to do
-        if (sh != 0ULL && (__ballot(mode == kStep) == 0ULL || __popcll(sh) >= shade_threshold)) {
+        if (sh != 0ULL && (__ballot(mode == kStep) == 0ULL || (int)__popcll(sh) >= shade_threshold)) {
             VRC_STAT(w_sh_passes, 1); VRC_STAT(w_sh_lanes, __popcll(sh));
             if (kMulti && mode == kRelight) {             // back to the first strike for the next light
                 r.light_index++;
