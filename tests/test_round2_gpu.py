@@ -106,8 +106,10 @@ def test_configs4_scene_200GB_resident_sampled_rows(atlas):
     the oracle, which reads the descriptors it needs from the GPU page by page."""
     depth, thickness, floor, w, h = 16, int(os.environ.get("VRC_C5_THICKNESS", "33")), 2, 7680, 4320
     dim = 1 << depth
+    # configs[4] row-tiles the frame over 8 GPUs with the SVO replicated: an 8-rank group handle, every rank on the one
+    # GPU this box has (ranks on rank 0's GPU share its 198 GB array; on an 8-GPU node each rank gets a peer copy)
     c = vrc.CLCaster()
-    assert c.init(0)
+    assert c.init_group([0] * 8, band_rows=8) and c.group_size() == 8
     rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     rng = np.random.default_rng(16)
     probe = rng.integers(0, dim, size=(256, 2)).astype(np.int32)
@@ -132,8 +134,12 @@ def test_configs4_scene_200GB_resident_sampled_rows(atlas):
     assert c.validate() and c.compute(), c.last_error()
     n_launch, ms = c.timing()
     ctr = c.counters()
-    print(f"configs[4] frame on one GPU: {ms / n_launch:.1f} ms, {ctr['primary_rays'] + ctr['shadow_rays']} rays, "
-          f"{ctr['steps'] / 1e9:.1f} G steps, {ctr['descriptor_reads'] / 1e6:.1f} M descriptor reads")
+    print(f"configs[4] frame, 8 row-sliced ranks on one GPU: slowest rank {ms / n_launch:.1f} ms of kernel time, "
+          f"{ctr['primary_rays'] + ctr['shadow_rays']} rays, {ctr['steps'] / 1e9:.1f} G steps, {ctr['descriptor_reads'] / 1e6:.1f} M descriptor reads")
+    mem = [c.memory_usage(r) for r in range(8)]
+    assert sum(m["rows"] for m in mem) == h and {m["rows"] for m in mem} == {536, 544}      # 540 bands of 8 rows over 8 ranks
+    assert all(m["image_bytes"] == 16 * w * m["rows"] for m in mem)
+    assert mem[0]["octree_bytes"] == info["n_descriptors"] * 8 and all(m["octree_shared"] == 1 for m in mem[1:])
     assert ctr["primary_rays"] == w * h and ctr["shadow_rays"] > w * h
     img, hits = c.read_image(), c.read_hits()
     assert ctr["descriptor_reads"] == int(hits[..., 7].astype(np.int64).sum())
@@ -246,6 +252,27 @@ def test_group_handle_is_one_synchronous_compute_over_all_ranks(ranks, atlas):
     info, _ = g.build_shell_terrain(10, 1, 2, 2)
     assert g.validate() and g.compute(), g.last_error()
     assert g.octree_size()[0] == info["n_descriptors"] and g.counters()["primary_rays"] == w * h
+
+
+def test_configs3_eight_rank_group_sampled_rows():
+    """BASELINE configs[3]: 4096^3, 3840x2160, 2 lights, row-tiled over 8 ranks with the SVO replicated -- an 8-rank group
+    handle (all ranks on this box's one GPU), sampled rows bit-exact vs the oracle, an eighth of the rows per rank."""
+    sc = bench_scene(12)
+    dim, w, h = sc["dim"], 3840, 2160
+    g = vrc.CLCaster()
+    assert g.init_group([0] * 8, band_rows=8) and g.assign_octree(sc["octree"])
+    configure(g, dim, sc["atlas"], sc["cam_dir"], sc["cam_pos"], sc["lights"], w, h, light_count=2)
+    assert g.validate() and g.compute(), g.last_error()
+    rows = [g.memory_usage(r)["rows"] for r in range(8)]
+    assert sum(rows) == h and set(rows) == {264, 272}                # 270 bands of 8 rows over 8 ranks
+    img, hits, ctr = g.read_image(), g.read_hits(), g.counters()
+    assert ctr["primary_rays"] == w * h and ctr["descriptor_reads"] == int(hits[..., 7].astype(np.int64).sum())
+    for y0 in range(17, h, 307):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=g._li, atlas=sc["atlas"],
+                                     tile_dim=(16, 16), descriptors=sc["octree"].descriptor_buffer, root_index=sc["octree"].root_index,
+                                     octree_dim=dim, using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=16, active_lights=2)
+        assert np.array_equal(hits[y0], ohits[y0])
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
 
 
 def test_group_with_more_ranks_than_row_bands(atlas):
