@@ -120,6 +120,15 @@ def make_caster(sc, width, height, device, table=None, shadow_rays=1, light_coun
 
 
 # --------------------------------------------------------------------------- distributed helpers
+def barrier(local_rank: int):
+    """dist.barrier on this rank's GPU (NCCL wants to be told the device; gloo has none)."""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[local_rank])
+    else:
+        dist.barrier()
+
+
 def reduce_over_ranks(rays: int, seconds: float):
     """(SUM of rays, MAX of seconds) over all ranks; identity when not distributed."""
     import torch
@@ -242,7 +251,7 @@ def main():
         raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
 
     # build BEFORE anything touches the GPU (a GPU-initialised process must not spawn compilers); under torchrun the
-    # local rank 0 builds, the others wait for its marker file
+    # local rank 0 builds, the others meet it at the first barrier below before they import the library
     import __graft_entry__ as graft
     if args.no_build:
         if graft.stale():
@@ -264,7 +273,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL: barrier + scalar reductions only
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
-        dist.barrier()                     # rank 0's build is finished before any other rank imports the library
+        barrier(local_rank)                # rank 0's build is finished before any other rank imports the library
     import voxel_raycaster_amd  # noqa: F401  (fails loudly if the HIP library is missing)
 
     sc, tree_file = shared_scene(args.depth, rank, world, os.environ.get("MASTER_PORT", "0"))
@@ -278,7 +287,7 @@ def main():
                     octree_file=None if rank == 0 else tree_file, hit_records=0)
     del table
     if world > 1:
-        dist.barrier()
+        barrier(local_rank)
         if rank == 0:
             os.remove(tree_file)
 
@@ -295,14 +304,14 @@ def main():
     c.timing_reset()
 
     if world > 1:
-        dist.barrier()
+        barrier(local_rank)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if not c.compute():
             raise SystemExit("compute failed: " + c.last_error())
     if world > 1:
-        dist.barrier()
+        barrier(local_rank)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
@@ -364,7 +373,7 @@ def main():
             out.update(supplementary(sc, c, W, H, local_rank, args, rays_per_step))
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier(local_rank)
         dist.destroy_process_group()
 
 
