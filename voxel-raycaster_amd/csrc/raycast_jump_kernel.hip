@@ -193,7 +193,8 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
                 r.vx = nx; r.vy = ny; r.vz = nz;
                 r.fmx = mx; r.fmy = my; r.fmz = mz;
                 t_exit = t;
-                if (nx >= p.map_dim[0] || ny >= p.map_dim[1] || nz >= p.map_dim[2] || nx < 0 || ny < 0 || nz < 0) {
+                // :563 any(voxel >= map_dim) || any(voxel < 0): one unsigned compare per axis covers both sides
+                if ((unsigned)nx >= (unsigned)p.map_dim[0] || (unsigned)ny >= (unsigned)p.map_dim[1] || (unsigned)nz >= (unsigned)p.map_dim[2]) {
                     oob_exit(r);                              // :563-568
                     mode = ended();
                 } else {

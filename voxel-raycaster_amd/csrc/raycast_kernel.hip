@@ -192,22 +192,22 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         const int size = 1 << b;
         const unsigned valid = (unsigned)cur & 0xffu;
         const int i = ((r.vx >> b) & 1) | (((r.vy >> b) & 1) << 1) | (((r.vz >> b) & 1) << 2);
-        // axis a can be widened when the ray moves from this half of the parent toward the other half
-        const unsigned ahead = (((i & 1) == 0) == (r.sx > 0) ? 1u : 0u) | ((((i >> 1) & 1) == 0) == (r.sy > 0) ? 2u : 0u) |
-                               ((((i >> 2) & 1) == 0) == (r.sz > 0) ? 4u : 0u);
-        auto span = [&](unsigned e) -> unsigned {                 // children covered when widening over the axes in e
-            unsigned m = 1u << i;
-            if (e & 1u) m |= ((m & 0x55u) << 1) | ((m & 0xaau) >> 1);
-            if (e & 2u) m |= ((m & 0x33u) << 2) | ((m & 0xccu) >> 2);
-            if (e & 4u) m |= ((m & 0x0fu) << 4) | ((m & 0xf0u) >> 4);
-            return m;
+        // axis a can be widened when the ray moves from this half of the parent toward the other half: child bit a differs
+        // from the sign bit of the step (voxel_step is +1 or -1, never 0)
+        const unsigned sgn = (unsigned)((r.sx + 1) >> 1) | (unsigned)((r.sy + 1) & 2) | ((unsigned)((r.sz + 1) & 2) << 1);
+        const unsigned ahead = ((unsigned)i ^ sgn) & 7u;
+        // children covered when widening over the axes in e = those that differ from i only in axes of e: the subsets of
+        // e as bit positions (one byte per e in the constant), shifted to i with the axes of e cleared
+        auto span = [&](unsigned e) -> unsigned {
+            return ((unsigned)(0xFF5533110F050301ULL >> (8u * e)) & 0xffu) << ((unsigned)i & ~e);
         };
+        auto pair = [&](unsigned e) -> unsigned { return (1u << i) | (1u << ((unsigned)i ^ e)); };   // span of one axis
         unsigned ext = 0;
         if (widen) {
             if ((span(ahead) & valid) == 0) ext = ahead;
-            else if ((ahead & 2u) && (span(2u) & valid) == 0) ext = 2u;
-            else if ((ahead & 1u) && (span(1u) & valid) == 0) ext = 1u;
-            else if ((ahead & 4u) && (span(4u) & valid) == 0) ext = 4u;
+            else if ((ahead & 2u) && (pair(2u) & valid) == 0) ext = 2u;
+            else if ((ahead & 1u) && (pair(1u) & valid) == 0) ext = 1u;
+            else if ((ahead & 4u) && (pair(4u) & valid) == 0) ext = 4u;
         }
         const int sx2 = (ext & 1u) ? 2 * size : size, sy2 = (ext & 2u) ? 2 * size : size, sz2 = (ext & 4u) ? 2 * size : size;
         const int cx = r.vx & ~(sx2 - 1), cy = r.vy & ~(sy2 - 1), cz = r.vz & ~(sz2 - 1);
