@@ -168,20 +168,18 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
         const bool do_jump = n_jump > 0 && (n_desc == 0 || n_jump * VRC_JUMP_VOTE_DEN >= n_desc * VRC_JUMP_VOTE_NUM);
         if (do_jump)
         if (mode == jStep) {
-            const float plx = (float)(r.sx > 0 ? cx + size : cx), ply = (float)(r.sy > 0 ? cy + size : cy),
-                        plz = (float)(r.sz > 0 ? cz + size : cz);
-            const float tx = (plx - ox) * ivx, ty = (ply - oy) * ivy, tz = (plz - oz) * ivz;
+            // straight-line code on purpose: both sides of every choice are a couple of instructions, a branch costs more
+            const int smx = (r.sx - 1) >> 1, smy = (r.sy - 1) >> 1, smz = (r.sz - 1) >> 1;   // 0 for step +1, -1 for step -1
+            const int pix = cx + (size & ~smx), piy = cy + (size & ~smy), piz = cz + (size & ~smz);   // the exit planes
+            const float tx = ((float)pix - ox) * ivx, ty = ((float)piy - oy) * ivy, tz = ((float)piz - oz) * ivz;
             float t = tx;
-            if (ty < t) t = ty;
-            if (tz < t) t = tz;
+            t = ty < t ? ty : t;
+            t = tz < t ? tz : t;
             const int mx = tx <= t, my = ty <= t, mz = tz <= t;
-            int nx, ny, nz;
-            if (mx) nx = r.sx > 0 ? cx + size : cx - 1;
-            else { nx = (int)floorf(ox + t * r.rdx); nx = nx < cx ? cx : (nx > cx + size - 1 ? cx + size - 1 : nx); }
-            if (my) ny = r.sy > 0 ? cy + size : cy - 1;
-            else { ny = (int)floorf(oy + t * r.rdy); ny = ny < cy ? cy : (ny > cy + size - 1 ? cy + size - 1 : ny); }
-            if (mz) nz = r.sz > 0 ? cz + size : cz - 1;
-            else { nz = (int)floorf(oz + t * r.rdz); nz = nz < cz ? cz : (nz > cz + size - 1 ? cz + size - 1 : nz); }
+            const int hi_x = cx + size - 1, hi_y = cy + size - 1, hi_z = cz + size - 1;
+            const int qx = min(max((int)floorf(ox + t * r.rdx), cx), hi_x), qy = min(max((int)floorf(oy + t * r.rdy), cy), hi_y),
+                      qz = min(max((int)floorf(oz + t * r.rdz), cz), hi_z);
+            const int nx = mx ? pix + smx : qx, ny = my ? piy + smy : qy, nz = mz ? piz + smz : qz;   // plane, or plane - 1 going down
             const int steps = abs(nx - r.vx) + abs(ny - r.vy) + abs(nz - r.vz);
             if (r.distance_traveled + steps - 1 >= r.max_distance) {     // the :357 guard ends the ray inside the node
                 c_steps += (unsigned)(r.max_distance - r.distance_traveled);
