@@ -28,31 +28,33 @@ __device__ __forceinline__ uint64_t jump_make_entry(const uint64_t *__restrict__
 enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4 };
 }  // namespace
 
-// blocks per CU the register budget is set for: 7 waves per SIMD (72 VGPRs, a handful of spills) measured fastest --
-// 5 / 6 / 7 blocks: 0.93 / 0.91 / 0.85 ms on the headline frame; the kernel waits on dependent loads half of the time
-// (profiles/r02_pmc_mode_b.txt), so residency beats spill-free registers.  LDS (22.5 KB of stack per block at depth 12)
-// allows 7 blocks per CU as well.
-// scheduling of the two blocks of a round (see the main loop); results never depend on it.  Measured on the headline
-// frame: both blocks every round 0.869 ms; jump block only when n_jump >= n_descend / 2 / 0.75 n_descend / n_descend:
-// 0.88 / 0.87 / 0.86 ms; the same votes without the descent block after a jump: 1.00 ms -- so the default stays "both".
-#ifndef VRC_JUMP_VOTE_NUM
-#define VRC_JUMP_VOTE_NUM 0          // 0: the jump block runs whenever a lane waits for it
-#define VRC_JUMP_VOTE_DEN 1
-#endif
-#ifndef VRC_DESCEND_AFTER_JUMP
-#define VRC_DESCEND_AFTER_JUMP 1     // 1: a round that jumped also runs the descent block
+// blocks per CU the register budget is set for: 8 waves per SIMD (64 VGPRs, 14 dwords of scratch) measured fastest --
+// 5 / 6 / 7 blocks: 0.93 / 0.91 / 0.85 ms on the headline frame with the first version of the kernel, 7 / 8 blocks
+// 0.678 / 0.667 ms with this one; the kernel waits on dependent loads half of the time (profiles/r02_pmc_mode_b.txt),
+// so residency beats spill-free registers.  LDS: 20 KB of stack per block at depth 12 (levels 1..10, the level-11 entry
+// is never popped to and is not stored), no static LDS -- 8 blocks fill the CU's 160 KB exactly.
+// The blocks one round runs, in order (see the main loop); results never depend on it.  VRC_J = the jump block,
+// VRC_D = one level of descent; the argument says whether the block runs unconditionally (true) or only when a lane of
+// the wave waits for it.  Measured on the headline frame (same box): J D 0.755 ms, J D D 0.700, J D D D ~0.74,
+// D J D 0.700, J D J D 0.758, (J D D) x 2 / x 3 / x 4 0.673 / 0.700 / 0.670 ms.
+// Dropped earlier: the jump block by majority vote of the wave (0.86-0.88 vs 0.869 ms then), votes without a descent
+// after the jump (1.00 ms); child indices kept in 32 bits for trees below 2^32 descriptors, masks and index in
+// separate words of the stack entry (+1 %); testing the landing node at the end of the jump block and after every
+// descent load instead of in a round of its own (halves the descent blocks a jump needs, yet +3 % with the best program).
+#ifndef VRC_ROUND_PROGRAM
+#define VRC_ROUND_PROGRAM VRC_J(true) VRC_D(true) VRC_D(true) VRC_J(true) VRC_D(true) VRC_D(true)
 #endif
 #ifndef VRC_JUMP_MIN_BLOCKS
-#define VRC_JUMP_MIN_BLOCKS (28 / VRC_TILES_PER_BLOCK)
+#define VRC_JUMP_MIN_BLOCKS (32 / VRC_TILES_PER_BLOCK)
 #endif
 
 template <bool kMulti>
 __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_jump_kernel(const RaycastParams p) {
-    extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
-    __shared__ unsigned long long block_ctr[kCtrCount];
+    extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-2
+    // the counter partials of the block reuse the stack's memory once every ray of the block has ended (no static LDS:
+    // 8 blocks of a depth-12 tree fill the CU's 160 KB exactly)
+    unsigned long long *const block_ctr = (unsigned long long *)lds_stack;
     const int tid = threadIdx.x;
-    if (tid < kCtrCount) block_ctr[tid] = 0;
-    __syncthreads();
 
     int px, py, brow;
     block_pixel(p, px, py, brow);
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
             const uint64_t d = descriptors[child];
             c_desc++;
             cur = jump_make_entry(descriptors, child, d);
-            lds_stack[top * kBlockThreads + tid] = cur;
+            if (top < n - 2) lds_stack[top * kBlockThreads + tid] = cur;     // the deepest entry is never popped to
             top++;
         }
     };
@@ -151,90 +153,102 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
     const int shade_threshold = kDefaultShadeThreshold;
     int rounds_left = p.watchdog_rounds;
 #ifdef VRC_SCHED_STATS
-    // profiling build only: lane-rounds by what the lane was doing when the round started
-    unsigned s_rounds = 0, s_step = 0, s_descend = 0, s_parked = 0, s_done = 0, s_shade_passes = 0;
+    // profiling build only: how often a wave ran each block and how many lanes had work in it
+    unsigned s_rounds = 0, s_jwaves = 0, s_jlanes = 0, s_dwaves = 0, s_dlanes = 0, s_shade_passes = 0;
 #endif
     for (;;) {
 #ifdef VRC_SCHED_STATS
         if ((tid & 63) == 0) s_rounds++;
-        s_step += mode == jStep; s_descend += mode == jDescend; s_parked += (mode == jShade || mode == jRelight); s_done += mode == jDone;
 #endif
-        // One round = one block of code for the lanes that wait for it: the node-exit JUMP (pure arithmetic + the pop to
-        // the common ancestor, an LDS read) or one level of the DESCENT toward the voxel a lane landed in (one dependent
-        // 8-byte load).  A jump is followed by ~2 descent steps on average, so running both blocks every round leaves the
-        // jump block 38 % full (tools/mode_b_stats.py); the wave votes instead: the jump block runs when at least
-        // VRC_JUMP_VOTE_NUM / VRC_JUMP_VOTE_DEN as many lanes wait to jump as wait to descend.
-        const int n_jump = __popcll(__ballot(mode == jStep)), n_desc = __popcll(__ballot(mode == jDescend));
-        const bool do_jump = n_jump > 0 && (n_desc == 0 || n_jump * VRC_JUMP_VOTE_DEN >= n_desc * VRC_JUMP_VOTE_NUM);
-        if (do_jump)
+        // One round = VRC_ROUND_PROGRAM: the node-exit JUMP (pure arithmetic + the pop to the common ancestor, an LDS
+        // read) for the lanes that wait for it, then levels of the DESCENT toward the voxel a lane landed in (one
+        // dependent 8-byte load each).  A jump is followed by ~2 descent steps on average (tools/mode_b_stats.py).
+        auto jump_block = [&]() {
+#ifdef VRC_SCHED_STATS
+        if ((tid & 63) == 0) s_jwaves++;
+        s_jlanes += mode == jStep;
+#endif
         if (mode == jStep) {
-            // straight-line code on purpose: both sides of every choice are a couple of instructions, a branch costs more
-            const int smx = (r.sx - 1) >> 1, smy = (r.sy - 1) >> 1, smz = (r.sz - 1) >> 1;   // 0 for step +1, -1 for step -1
-            const int pix = cx + (size & ~smx), piy = cy + (size & ~smy), piz = cz + (size & ~smz);   // the exit planes
-            const float tx = ((float)pix - ox) * ivx, ty = ((float)piy - oy) * ivy, tz = ((float)piz - oz) * ivz;
-            float t = tx;
-            t = ty < t ? ty : t;
-            t = tz < t ? tz : t;
-            const int mx = tx <= t, my = ty <= t, mz = tz <= t;
-            const int hi_x = cx + size - 1, hi_y = cy + size - 1, hi_z = cz + size - 1;
-            const int qx = min(max((int)floorf(ox + t * r.rdx), cx), hi_x), qy = min(max((int)floorf(oy + t * r.rdy), cy), hi_y),
-                      qz = min(max((int)floorf(oz + t * r.rdz), cz), hi_z);
-            const int nx = mx ? pix + smx : qx, ny = my ? piy + smy : qy, nz = mz ? piz + smz : qz;   // plane, or plane - 1 going down
-            const int steps = abs(nx - r.vx) + abs(ny - r.vy) + abs(nz - r.vz);
-            if (r.distance_traveled + steps - 1 >= r.max_distance) {     // the :357 guard ends the ray inside the node
-                c_steps += (unsigned)(r.max_distance - r.distance_traveled);
-                r.distance_traveled = r.max_distance;
-                mode = ended();
-            } else {
-                c_steps += (unsigned)steps;
-                r.distance_traveled += steps - 1;
-                r.vx = nx; r.vy = ny; r.vz = nz;
-                r.fmx = mx; r.fmy = my; r.fmz = mz;
-                t_exit = t;
-                // :563 any(voxel >= map_dim) || any(voxel < 0): one unsigned compare per axis covers both sides
-                if ((unsigned)nx >= (unsigned)p.map_dim[0] || (unsigned)ny >= (unsigned)p.map_dim[1] || (unsigned)nz >= (unsigned)p.map_dim[2]) {
-                    oob_exit(r);                              // :563-568
+                // straight-line code on purpose: both sides of every choice are a couple of instructions, a branch costs more
+                const int smx = (r.sx - 1) >> 1, smy = (r.sy - 1) >> 1, smz = (r.sz - 1) >> 1;   // 0 for step +1, -1 for step -1
+                const int pix = cx + (size & ~smx), piy = cy + (size & ~smy), piz = cz + (size & ~smz);   // the exit planes
+                const float tx = ((float)pix - ox) * ivx, ty = ((float)piy - oy) * ivy, tz = ((float)piz - oz) * ivz;
+                float t = tx;
+                t = ty < t ? ty : t;
+                t = tz < t ? tz : t;
+                const int mx = tx <= t, my = ty <= t, mz = tz <= t;
+                const int hi_x = cx + size - 1, hi_y = cy + size - 1, hi_z = cz + size - 1;
+                const int qx = min(max((int)floorf(ox + t * r.rdx), cx), hi_x), qy = min(max((int)floorf(oy + t * r.rdy), cy), hi_y),
+                          qz = min(max((int)floorf(oz + t * r.rdz), cz), hi_z);
+                const int nx = mx ? pix + smx : qx, ny = my ? piy + smy : qy, nz = mz ? piz + smz : qz;   // plane, or plane - 1 going down
+                const int steps = abs(nx - r.vx) + abs(ny - r.vy) + abs(nz - r.vz);
+                if (r.distance_traveled + steps - 1 >= r.max_distance) {     // the :357 guard ends the ray inside the node
+                    c_steps += (unsigned)(r.max_distance - r.distance_traveled);
+                    r.distance_traveled = r.max_distance;
                     mode = ended();
                 } else {
-                    // pop to the deepest level whose node holds both the voxel located last and the new one (after a
-                    // redirect the two are not neighbours: the cursor still sits at the hit voxel)
-                    const unsigned diff = (unsigned)((nx ^ pvx) | (ny ^ pvy) | (nz ^ pvz));
-                    if (top > 0 && (diff >> (n - top)) != 0) {
-                        top = n - (31 - __clz((int)diff)) - 1;
-                        cur = (top == 0) ? root_entry : lds_stack[(top - 1) * kBlockThreads + tid];
+                    c_steps += (unsigned)steps;
+                    r.distance_traveled += steps - 1;
+                    r.vx = nx; r.vy = ny; r.vz = nz;
+                    r.fmx = mx; r.fmy = my; r.fmz = mz;
+                    t_exit = t;
+                    // :563 any(voxel >= map_dim) || any(voxel < 0): one unsigned compare per axis covers both sides
+                    if ((unsigned)nx >= (unsigned)p.map_dim[0] || (unsigned)ny >= (unsigned)p.map_dim[1] || (unsigned)nz >= (unsigned)p.map_dim[2]) {
+                        oob_exit(r);                              // :563-568
+                        mode = ended();
+                    } else {
+                        // pop to the deepest level whose node holds both the voxel located last and the new one (after a
+                        // redirect the two are not neighbours: the cursor still sits at the hit voxel)
+                        const unsigned diff = (unsigned)((nx ^ pvx) | (ny ^ pvy) | (nz ^ pvz));
+                        if (top > 0 && (diff >> (n - top)) != 0) {
+                            top = n - (31 - __clz((int)diff)) - 1;
+                            cur = (top == 0) ? root_entry : lds_stack[(top - 1) * kBlockThreads + tid];
+                        }
+                        pvx = nx; pvy = ny; pvz = nz;
+                        mode = jDescend;
                     }
-                    pvx = nx; pvy = ny; pvz = nz;
-                    mode = jDescend;
                 }
             }
-        }
-        if ((!do_jump || VRC_DESCEND_AFTER_JUMP) && mode == jDescend) {
-            const int b = n - top - 1;
-            const int i = ((r.vx >> b) & 1) | (((r.vy >> b) & 1) << 1) | (((r.vz >> b) & 1) << 2);
-            const unsigned masks = (unsigned)cur & 0xffffu;
-            const unsigned bit = 1u << i;
-            if (!(masks & bit)) {                             // the voxel lies in an empty node of size 2^b
-                set_node(1 << b);
-                r.distance_traveled++;                        // :714
-                mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
-            } else if (((masks >> 8) & bit) || b == 0) {      // solid
-                set_node(1);
-                const int m5 = solid_material(r.vx, r.vy, r.vz);
-                if (m5 == 5 || m5 == 6) {                     // :575
-                    mode = jShade;                            // the hit block is deferred (the material is looked up again there)
-                } else {                                      // any other material is passed through
-                    r.distance_traveled++;
+        };
+        auto descend_block = [&]() {
+#ifdef VRC_SCHED_STATS
+        if ((tid & 63) == 0) s_dwaves++;
+        s_dlanes += mode == jDescend;
+#endif
+        if (mode == jDescend) {
+                const int b = n - top - 1;
+                const int i = ((r.vx >> b) & 1) | (((r.vy >> b) & 1) << 1) | (((r.vz >> b) & 1) << 2);
+                const unsigned masks = (unsigned)cur & 0xffffu;
+                const unsigned bit = 1u << i;
+                if (!(masks & bit)) {                             // the voxel lies in an empty node of size 2^b
+                    set_node(1 << b);
+                    r.distance_traveled++;                        // :714
                     mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
+                } else if (((masks >> 8) & bit) || b == 0) {      // solid
+                    set_node(1);
+                    const int m5 = solid_material(r.vx, r.vy, r.vz);
+                    if (m5 == 5 || m5 == 6) {                     // :575
+                        mode = jShade;                            // the hit block is deferred (the material is looked up again there)
+                    } else {                                      // any other material is passed through
+                        r.distance_traveled++;
+                        mode = (r.distance_traveled < r.max_distance) ? jStep : ended();
+                    }
+                } else {                                          // one level down: one dependent load
+                    const uint64_t child = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
+                    const uint64_t d = descriptors[child];
+                    c_desc++;
+                    cur = jump_make_entry(descriptors, child, d);
+                    if (top < n - 2) lds_stack[top * kBlockThreads + tid] = cur;     // the deepest entry is never popped to
+                    top++;
                 }
-            } else {                                          // one level down: one dependent load
-                const uint64_t child = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
-                const uint64_t d = descriptors[child];
-                c_desc++;
-                cur = jump_make_entry(descriptors, child, d);
-                lds_stack[top * kBlockThreads + tid] = cur;
-                top++;
             }
-        }
+        };
+        // later blocks of the round run only if some lane of the wave waits for them (a wave-uniform branch)
+#define VRC_J(always) if ((always) || __ballot(mode == jStep) != 0ULL) jump_block();
+#define VRC_D(always) if ((always) || __ballot(mode == jDescend) != 0ULL) descend_block();
+        VRC_ROUND_PROGRAM
+#undef VRC_J
+#undef VRC_D
         const unsigned long long st = __ballot(mode == jStep || mode == jDescend);
         const unsigned long long sh = __ballot(mode == jShade || (kMulti && mode == jRelight));
         if ((st | sh) == 0ULL || --rounds_left < 0) break;
@@ -273,6 +287,9 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
         }
     }
 
+    __syncthreads();
+    if (tid < kCtrCount) block_ctr[tid] = 0;
+    __syncthreads();
     if (rounds_left < 0 && (tid & 63) == 0) {
         atomicAdd(&block_ctr[kCtrWatchdog], 1ULL);
         if (p.watchdog_flag) __hip_atomic_store(p.watchdog_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -287,11 +304,11 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
     }
 #ifdef VRC_SCHED_STATS
     atomicAdd(&block_ctr[kCtrWaveIters], (unsigned long long)s_rounds);
-    atomicAdd(&block_ctr[kCtrBursts], (unsigned long long)s_step);
-    atomicAdd(&block_ctr[kCtrEventPasses], (unsigned long long)s_descend);
-    atomicAdd(&block_ctr[kCtrEventLanes], (unsigned long long)s_parked);
+    atomicAdd(&block_ctr[kCtrBursts], (unsigned long long)s_jwaves);
+    atomicAdd(&block_ctr[kCtrEventPasses], (unsigned long long)s_jlanes);
+    atomicAdd(&block_ctr[kCtrEventLanes], (unsigned long long)s_dwaves);
     atomicAdd(&block_ctr[kCtrShadePasses], (unsigned long long)s_shade_passes);
-    atomicAdd(&block_ctr[kCtrShadeLanes], (unsigned long long)s_done);
+    atomicAdd(&block_ctr[kCtrShadeLanes], (unsigned long long)s_dlanes);
 #endif
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
     publish_counters(p, block_ctr, vals);
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
 hipError_t launch_raycast_jump(const RaycastParams &p, hipStream_t stream) {
     const int nblocks = p.blocks_x * p.local_tile_rows;
     if (nblocks <= 0) return hipSuccess;
-    const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
+    const int levels = p.log2_dim > 2 ? p.log2_dim - 2 : 1;     // >= the counter partials that reuse the memory
     const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t);
     if (p.light_count > 1) hipLaunchKernelGGL((raycast_jump_kernel<true>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
     else hipLaunchKernelGGL((raycast_jump_kernel<false>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
