@@ -52,6 +52,28 @@ DEFK(fma, OP_FMA) DEFK(add, OP_ADD) DEFK(mul, OP_MUL) DEFK(fmac, OP_FMAC) DEFK(f
 DEFK(min3, OP_MIN3) DEFK(maxf, OP_MAX) DEFK(cmp, OP_CMP) DEFK(cnds, OP_CNDS) DEFK(cvt, OP_CVT) DEFK(addu, OP_ADDU)
 DEFK(andb, OP_AND) DEFK(lshl, OP_LSHL) DEFK(mov, OP_MOV) DEFK(rcp, OP_RCP) DEFK(madu, OP_MADU) DEFK(bfe, OP_BFE) DEFK(sub, OP_SUB)
 
+// packed f32 (two f32 operations per lane and instruction, 64-bit register pairs)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define BODY2(OP)                                                                                          \
+    REP8(asm volatile(OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)                                       \
+                      : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k0), "v"(k1));)
+#define DEFK2(name, OP)                                                                                    \
+__global__ __launch_bounds__(256) void k_##name(float *out, unsigned long long *cyc, int iters) {          \
+    f32x2 r0 = {threadIdx.x + 1.0f, 2.0f}, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7; \
+    f32x2 k0 = {1.0001f, 1.0002f}, k1 = {0.5f, 0.25f};                                                      \
+    const unsigned long long t0 = __builtin_readcyclecounter();                                             \
+    for (int i = 0; i < iters; i++) { BODY2(OP) }                                                           \
+    const unsigned long long t1 = __builtin_readcyclecounter();                                             \
+    const f32x2 s = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;                                                  \
+    out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y;                                                        \
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                       \
+}
+#define OP_PKFMA(i)   "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_PKFMACL(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9 clamp\n"
+#define OP_PKADD(i)   "v_pk_add_f32 %" #i ", %" #i ", %9\n"
+#define OP_PKMUL(i)   "v_pk_mul_f32 %" #i ", %" #i ", %8\n"
+DEFK2(pkfma, OP_PKFMA) DEFK2(pkfmacl, OP_PKFMACL) DEFK2(pkadd, OP_PKADD) DEFK2(pkmul, OP_PKMUL)
+
 typedef void (*kern_t)(float *, unsigned long long *, int);
 
 int main() {
@@ -60,7 +82,8 @@ int main() {
         {"v_fma_f32 clamp", k_fmaclamp}, {"v_min_f32", k_minf}, {"v_min3_f32", k_min3}, {"v_max_f32", k_maxf},
         {"v_cmp_le_f32 vcc", k_cmp}, {"v_cndmask_b32 (sgpr)", k_cnds}, {"v_cvt_i32_f32", k_cvt}, {"v_add_u32", k_addu},
         {"v_and_b32", k_andb}, {"v_lshlrev_b32", k_lshl}, {"v_mov_b32", k_mov}, {"v_rcp_f32", k_rcp},
-        {"v_mad_u32_u24", k_madu}, {"v_bfe_u32", k_bfe}};
+        {"v_mad_u32_u24", k_madu}, {"v_bfe_u32", k_bfe},
+        {"v_pk_fma_f32", k_pkfma}, {"v_pk_fma_f32 clamp", k_pkfmacl}, {"v_pk_add_f32", k_pkadd}, {"v_pk_mul_f32", k_pkmul}};
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
     const int iters = 256;                                  // 256 x 64 = 16384 instructions per wave between the two clock reads

@@ -44,6 +44,11 @@ enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4 };
 #ifndef VRC_ROUND_PROGRAM
 #define VRC_ROUND_PROGRAM VRC_J(true) VRC_D(true) VRC_D(true) VRC_J(true) VRC_D(true) VRC_D(true)
 #endif
+#ifndef VRC_JUMP_SHADE_THRESHOLD
+// lanes that must wait for the hit block before a wave with stepping lanes runs it: 8 / 16 / 32 / 48 / 64 measured
+// 0.83 / 0.81 / 0.78 / 0.80 / 0.665 ms (64 = only when no lane of the wave has anything cheaper to do)
+#define VRC_JUMP_SHADE_THRESHOLD kDefaultShadeThreshold
+#endif
 #ifndef VRC_JUMP_MIN_BLOCKS
 #define VRC_JUMP_MIN_BLOCKS (32 / VRC_TILES_PER_BLOCK)
 #endif
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
         }
     }
 
-    const int shade_threshold = kDefaultShadeThreshold;
+    const int shade_threshold = VRC_JUMP_SHADE_THRESHOLD;
     int rounds_left = p.watchdog_rounds;
 #ifdef VRC_SCHED_STATS
     // profiling build only: how often a wave ran each block and how many lanes had work in it
