@@ -41,6 +41,10 @@ enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4 };
 // after the jump (1.00 ms); child indices kept in 32 bits for trees below 2^32 descriptors, masks and index in
 // separate words of the stack entry (+1 %); testing the landing node at the end of the jump block and after every
 // descent load instead of in a round of its own (halves the descent blocks a jump needs, yet +3 % with the best program).
+// Also dropped (round 2, s_memtime per block: 60 % of a wave's time passes in the descent blocks, 32 % in the jump
+// blocks, 3 % in the hit block): the descent load issued before the jump block and used after it (+4 %: the latency is
+// already covered by the other 7 waves of the SIMD); load instructions batched by a vote of the wave until 8 / 16 / 32
+// lanes wait (+17 / +23 / +40 %: an idle lane costs more than a thin load).
 #ifndef VRC_ROUND_PROGRAM
 #define VRC_ROUND_PROGRAM VRC_J(true) VRC_D(true) VRC_D(true) VRC_J(true) VRC_D(true) VRC_D(true)
 #endif
