@@ -299,6 +299,20 @@ def diamond_square(dim: int, corner_seed: float = 58.0, want_grid: bool = True):
     return height, grid
 
 
+def pin_host_buffer(a: np.ndarray) -> None:
+    """vrc_pin_host_buffer: page-lock a caller-owned frame buffer so that read_image*(out=a) copies by DMA without a
+    staging pass (the reference shares a GL texture instead, src/CLCaster.cpp:278-296)."""
+    rc = lib.vrc_pin_host_buffer(C.c_void_p(a.ctypes.data), a.nbytes)
+    if rc != 0:
+        raise VrcError(f"vrc_pin_host_buffer: {STATUS.get(rc, rc)}")
+
+
+def unpin_host_buffer(a: np.ndarray) -> None:
+    rc = lib.vrc_unpin_host_buffer(C.c_void_p(a.ctypes.data))
+    if rc != 0:
+        raise VrcError(f"vrc_unpin_host_buffer: {STATUS.get(rc, rc)}")
+
+
 def synthetic_atlas(width: int = 256, height: int = 256) -> np.ndarray:
     a = np.zeros((height, width, 4), dtype=np.uint8)
     rc = lib.vrc_scene_atlas(width, height, _ptr(a, _u8p))
