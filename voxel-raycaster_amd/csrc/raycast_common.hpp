@@ -184,6 +184,13 @@ __device__ __forceinline__ bool more_lights(const Ray &r, const RaycastParams &p
     return r.shadow_ray && r.written && p.shadow_rays && r.light_index + 1 < p.light_count;
 }
 
+// :707-710: all the hit block does for a shadow ray that struck a voxel (the face arithmetic before it has no reader);
+// the kernels do it where the ray lands instead of parking the lane for a hit-block pass, then break (:710)
+__device__ __forceinline__ void shadow_hit(Ray &r) {
+    r.color_accumulator[3] = 0.1f;
+    r.flags |= kFlagShadowHit;
+}
+
 // :575-711 for voxel_data in {5, 6}.  Returns true when the loop breaks / the
 // kernel returns, false when the (redirected) ray keeps stepping.
 template <bool kMulti>

@@ -36,6 +36,10 @@
 #include "raycast_common.hpp"
 #include "safe_run.hpp"
 
+#ifndef VRC_RELIGHT_THRESHOLD
+#define VRC_RELIGHT_THRESHOLD 64      // lanes that must wait for the next light before a wave with stepping lanes serves them
+#endif
+
 namespace vrc {
 
 // Packed stack entry of one descriptor level:
@@ -469,7 +473,11 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
                         mode = (r.distance_traveled < r.max_distance) ? kStep : ended();   // :357
                     } else {
                         mat = solid_material(r.vx, r.vy, r.vz);
-                        if (mat == 5 || mat == 6) {       // :575
+                        if ((mat == 5 || mat == 6) && r.shadow_ray) {   // :575, :707-710
+                            shadow_hit(r);
+                            broke = 1;
+                            mode = ended();
+                        } else if (mat == 5 || mat == 6) {
                             mode = kShade;                // the hit block is deferred
                         } else {                          // any other material is passed through
                             enter_single();
@@ -482,11 +490,13 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
             sh = __ballot(mode == kShade || (kMulti && mode == kRelight));
         }
 
-        // ---- phase 4: hit block (:575-711): expensive and needed ~twice per pixel, so it runs only when
-        // many lanes wait for it or nothing cheaper is left to do
-        if (sh != 0ULL && (__ballot(mode == kStep) == 0ULL || (int)__popcll(sh) >= shade_threshold)) {
-            VRC_STAT(w_sh_passes, 1); VRC_STAT(w_sh_lanes, __popcll(sh));
-            if (kMulti && mode == kRelight) {             // back to the first strike for the next light
+        // ---- phase 4a (multi-light): a lane whose shadow ray has ended goes back to the first strike for the next light;
+        // cheap next to the hit block, so it need not wait for the whole tile (VRC_RELIGHT_THRESHOLD lanes, or nothing left
+        // to step)
+        if (kMulti) {
+            const unsigned long long rl = __ballot(mode == kRelight);
+            if (rl != 0ULL && ((int)__popcll(rl) >= VRC_RELIGHT_THRESHOLD || __ballot(mode == kStep) == 0ULL)) {
+            if (mode == kRelight) {
                 r.light_index++;
                 if (!light_from_strike(r, p, r.light_index, true)) {
                     mode = kDone;                         // :671-672, pixel left unwritten
@@ -500,7 +510,17 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
                     r.distance_traveled = r.kdist + 1;    // as if the strike iteration had just finished (:714)
                     mode = (r.distance_traveled < r.max_distance) ? kStep : ended();
                 }
-            } else if (mode == kShade) {
+            }
+            }
+            sh = __ballot(mode == kShade);
+        } else {
+            sh = __ballot(mode == kShade);
+        }
+        // ---- phase 4b: hit block (:575-711): expensive and needed once per pixel (a shadow ray's hit is handled where it
+        // lands), so it runs only when the whole tile waits for it or nothing cheaper is left to do
+        if (sh != 0ULL && (__ballot(mode == kStep) == 0ULL || (int)__popcll(sh) >= shade_threshold)) {
+            VRC_STAT(w_sh_passes, 1); VRC_STAT(w_sh_lanes, __popcll(sh));
+            if (mode == kShade) {
                 if (hit_block<kMulti>(r, mat, p)) {
                     broke = 1;
                     mode = ended();
