@@ -375,6 +375,10 @@ namespace {
 // Give every other rank of the group rank 0's tree: shared when the rank sits on the same GPU, copied device to
 // device otherwise (hipMemcpyPeerAsync: xGMI, no host staging; SURVEY 8e "peer fan-out").
 int fan_out_tree(vrc_caster *h) {
+    if (!h->peers.empty()) {                                   // the copies run on the peers' streams: rank 0's tree must be complete
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     for (size_t i = 0; i < h->peers.size(); i++) {
         vrc_caster *q = h->peers[i];
         release_tree(q);
