@@ -403,3 +403,31 @@ def test_hit_records_can_be_switched_off(atlas):
     img = c.read_image()
     assert c.overwrite_setting("hit_records", 1) and c.compute()
     assert np.array_equal(c.read_image().view(np.uint32), img.view(np.uint32)) and c.read_hits()[..., 3].max() == 5
+
+
+def test_read_back_into_a_pinned_caller_buffer(atlas):
+    """vrc_pin_host_buffer: the draw() replacement may page-lock its frame buffer once; the read-back calls then copy
+    straight into it -- same bytes as the pageable path (tools/readback_rate.py times the two)."""
+    s = scenes.floor_pillars()
+    dim, w, h = s["dim"], 160, 120
+    m = vrc.Map(dim, s["grid"])
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = s["lights"]
+    c = vrc.CLCaster()
+    assert c.init(0) and c.assign_octree(m.octree)
+    configure(c, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
+    assert c.validate() and c.compute()
+    img, rgba = c.read_image(), c.read_image_rgba8()
+    pin_img, pin_rgba = np.zeros_like(img), np.zeros_like(rgba)
+    vrc.pin_host_buffer(pin_img)
+    vrc.pin_host_buffer(pin_rgba)
+    try:
+        c.read_image(out=pin_img)
+        c.read_image_rgba8(out=pin_rgba)
+        assert np.array_equal(pin_img.view(np.uint32), img.view(np.uint32)) and np.array_equal(pin_rgba, rgba)
+        assert np.array_equal(pin_rgba, orc.image_to_rgba8(img))
+    finally:
+        vrc.unpin_host_buffer(pin_img)
+        vrc.unpin_host_buffer(pin_rgba)
+    with pytest.raises(vrc.VrcError):
+        vrc.unpin_host_buffer(pin_img)               # not pinned any more
