@@ -4,8 +4,8 @@
 // intersection_t += delta_t * jump_power * fabs(face_mask), the correction of the other axes commented out).  This
 // kernel does that jump the stateless way: the exit of  origin + t * ray_dir  from the empty node it is in is
 // t = min_a (plane_a - origin_a) / ray_dir_a.  One node event costs ~100 instructions instead of ~120 DDA steps, so
-// the frame is bound by the descriptor chain (dependent 8-byte loads), not by VALU issue: this is the mode that puts
-// the memory-side design under load.  It is NOT the reference's float sequence (the reference accumulates
+// the frame is bound by the chain of node events (jump arithmetic, pop, one dependent 8-byte load per level of descent)
+// each ray has to get through, not by the float recurrence: this is the mode that puts the memory-side design under load.  It is NOT the reference's float sequence (the reference accumulates
 // intersection_t by repeated addition and the hit block reads the accumulated rounding back, :592-614), so it is a
 // labelled, opt-in mode (setting stepping_mode = 1), never the headline: its parity statement is bit-exactness against
 // its own restatement in oracle/vrc_oracle.c (jump_step & co, same definitions, cited there) plus mismatch statistics
