@@ -42,9 +42,14 @@ KERNEL_SOURCES = ("raycast_kernel.hip", "raycast_jump_kernel.hip", "raycast_comm
 def kernel_source_hash() -> str:
     """Identifies the kernel a committed PMC measurement belongs to (profiles/traffic_latest.json carries it)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "voxel-raycaster_amd", "csrc", name), "rb").read())
+        text = open(os.path.join(ROOT, "voxel-raycaster_amd", "csrc", name), "r").read()
+        # comments and blank space are not code: a reworded comment must not orphan a measurement
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = "\n".join(l for l in (re.sub(r"//.*$", "", ln).rstrip() for ln in text.splitlines()) if l)
+        h.update(text.encode())
     return h.hexdigest()[:16]
 
 
