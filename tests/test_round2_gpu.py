@@ -431,3 +431,36 @@ def test_read_back_into_a_pinned_caller_buffer(atlas):
         vrc.unpin_host_buffer(pin_rgba)
     with pytest.raises(vrc.VrcError):
         vrc.unpin_host_buffer(pin_img)               # not pinned any more
+
+
+TINY_VIEWPORTS = [(1, 1), (1, 9), (9, 1), (3, 5), (8, 8), (65, 9)]
+
+
+@pytest.mark.parametrize("path", ["array", "svo_exact", "svo_mode_b"])
+@pytest.mark.parametrize("res", TINY_VIEWPORTS, ids=[f"{w}x{h}" for w, h in TINY_VIEWPORTS])
+def test_tiny_and_ragged_viewports(res, path, atlas):
+    """Viewports smaller than one 8x8 wave tile / one 32x8 block and not multiples of either: every pixel of the frame
+    equals the oracle in all three stepping paths, and the same frame comes out of a 3-rank group of row slices."""
+    from test_parity_gpu import make_caster, assert_same
+    s = scenes.floor_pillars()
+    dim, (w, h) = s["dim"], res
+    m = vrc.Map(dim, s["grid"])
+    using_octree = 1 if path == "array" else 0
+    mode = 1 if path == "svo_mode_b" else 0
+    c = make_caster(m.octree, dim, using_octree, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, 3 * dim, grid=s["grid"])
+    assert c.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", mode) and c.compute(), c.last_error()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=c._li, atlas=atlas,
+                                    tile_dim=(16, 16), descriptors=m.octree.descriptor_buffer, root_index=m.octree.root_index,
+                                    octree_dim=dim, using_octree=using_octree, grid=s["grid"], max_distance=3 * dim,
+                                    stepping_mode=mode)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+    assert np.array_equal(c.read_image_rgba8(), orc.image_to_rgba8(oimg))
+    g = vrc.CLCaster()
+    assert g.init_group([0, 0, 0], band_rows=8)
+    assert g.assign_octree(m.octree) and g.assign_map(s["grid"], (dim, dim, dim))
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = s["lights"]
+    configure(g, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
+    assert g.overwrite_setting("using_octree", using_octree) and g.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", mode)
+    assert g.validate() and g.compute(), g.last_error()
+    assert np.array_equal(g.read_hits(), ohits) and np.array_equal(g.read_image().view(np.uint32), oimg.view(np.uint32))
