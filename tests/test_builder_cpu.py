@@ -81,3 +81,17 @@ def test_host_builders_under_sanitizers(tmp_path):
     out = subprocess.run([exe, str(tmp_path / "t.svo")], capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0 and "host sanitize ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_hand_laid_sparse_tree_encodes_the_same_octree_as_the_builder():
+    """tests/treetools.sparse_octree (the deepest-tree GPU tests lay their 24-level trees with it) against the product's
+    builder on grids it can build: same octree, whatever the storage order."""
+    import treetools
+    rng = np.random.default_rng(11)
+    for depth, p in ((3, 0.2), (4, 0.05), (5, 0.01)):
+        dim = 1 << depth
+        g = (rng.random((dim, dim, dim)) < p).astype(np.int8) * 5
+        vox = [(x, y, z) for z in range(dim) for y in range(dim) for x in range(dim) if g[z, y, x]]
+        d, r = treetools.sparse_octree(vox, depth)
+        o = vrc.Octree.Generate(g.reshape(-1), dim, buffer_size=0, strict_reference=False)
+        assert treetools.canonical(d, r, dim)[0] == treetools.canonical(o.descriptor_buffer, o.root_index, dim)[0]

@@ -464,3 +464,35 @@ def test_tiny_and_ragged_viewports(res, path, atlas):
     assert g.overwrite_setting("using_octree", using_octree) and g.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", mode)
     assert g.validate() and g.compute(), g.last_error()
     assert np.array_equal(g.read_hits(), ohits) and np.array_equal(g.read_image().view(np.uint32), oimg.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["exact", "mode_b"])
+@pytest.mark.parametrize("depth", [20, 24], ids=["d20", "d24-deepest-the-stack-allows"])
+def test_deepest_trees(depth, mode, atlas):
+    """Maximum depth: a hand-laid tree of 20 / 24 levels (kMaxLevels = 24: dim 16 777 216) that holds one small
+    scene a million voxels from the origin -- the LDS stack at its largest, voxel coordinates at the edge of what a
+    float carries exactly, both stepping modes against the oracle, every pixel."""
+    from test_parity_gpu import assert_same
+    import treetools
+    dim = 1 << depth
+    bx, by, bz = (1000000, 1000000, 1000000) if depth == 24 else (300000, 700000, 500000)
+    vox = [(bx + x, by + y, bz) for x in range(-20, 21) for y in range(-20, 21)]                  # a floor
+    vox += [(bx + x, by + y, bz - 1) for x in range(-20, 21) for y in range(-20, 21)]
+    vox += [(bx + px, by + py, bz + 1 + k) for px, py in ((-6, 3), (5, 9), (2, -7)) for k in range(7)]   # pillars
+    desc, root = treetools.sparse_octree(vox, depth)
+    oct_ = vrc.Octree(desc, root, dim)
+    cam_dir, cam_pos = (1.85, 1.5708), (bx + 0.375, by - 14.625, bz + 9.25)    # the slab's far edge crosses the frame
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[0] = [0.01, 0.01, 0.01, 0.2, bx + 11.5, by - 5.25, bz + 17.75, -1.0, -1.0, -1.5]
+    w, h, md = 320, 200, 700
+    c = vrc.CLCaster()
+    assert c.init(0) and c.assign_octree(oct_)
+    configure(c, dim, atlas, cam_dir, cam_pos, li, w, h)
+    assert c.overwrite_setting("max_distance", md) and c.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", mode)
+    assert c.validate() and c.compute(), c.last_error()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=li, atlas=atlas, tile_dim=(16, 16),
+                                    descriptors=desc, root_index=root, octree_dim=dim, using_octree=0, max_distance=md,
+                                    stepping_mode=mode)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+    hit = float((ohits[..., 3] == 5).mean())
+    assert 0.5 < hit < 0.9 and octr["shadow_rays"] > 0       # slab and pillars below, 700 steps of 2^23-voxel nodes above

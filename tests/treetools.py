@@ -30,3 +30,39 @@ def canonical(desc: np.ndarray, root: int, dim: int):
         return (valid, leaf, tuple(kids))
 
     return node(root, dim), tuple(stats)
+
+
+def sparse_octree(voxels, depth: int):
+    """Descriptor array (reference format, include/map/Octree.h:89-94) of a tree of any depth that holds just the given
+    solid voxels: root first, every node's kept children in one block in slot order (i = x | y<<1 | z<<2), blocks in
+    breadth-first order, near pointers only.  Bottom level: valid = occupancy, leaf = 0xFF; above: valid for a kept
+    child, leaf for an empty one.  Returns (descriptors, root_index)."""
+    dim = 1 << depth
+
+    def build(vs, size):                                  # nested dict: slot -> subtree (or occupancy byte at size 2)
+        half = size // 2
+        buckets = {}
+        for (x, y, z) in vs:
+            i = (x >= half) | ((y >= half) << 1) | ((z >= half) << 2)
+            buckets.setdefault(int(i), []).append((x % half, y % half, z % half))
+        if size == 2:
+            return sum(1 << i for i in buckets)
+        return {i: build(b, half) for i, b in buckets.items()}
+
+    for v in voxels:
+        assert all(0 <= c < dim for c in v)
+    root = build([tuple(int(c) for c in v) for v in voxels], dim)
+    out, queue = [0], [(0, root, dim)]                    # slot 0 = root; breadth-first
+    while queue:
+        index, node, size = queue.pop(0)
+        if size == 2:
+            out[index] = (node << 16) | (0xff << 24)
+            continue
+        valid = sum(1 << i for i in node)
+        first = len(out)
+        assert first - index < 0x8000, "sparse_octree: near pointers only"
+        for i in sorted(node):
+            queue.append((len(out), node[i], size // 2))
+            out.append(0)
+        out[index] = (first - index) | (valid << 16) | ((~valid & 0xff) << 24)
+    return np.array(out, dtype=np.uint64), 0
