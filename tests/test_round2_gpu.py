@@ -496,3 +496,43 @@ def test_deepest_trees(depth, mode, atlas):
     assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
     hit = float((ohits[..., 3] == 5).mean())
     assert 0.5 < hit < 0.9 and octr["shadow_rays"] > 0       # slab and pillars below, 700 steps of 2^23-voxel nodes above
+
+
+ATLAS_SHAPES = [(192, 128, (24, 8)), (64, 64, (16, 16)), (300, 200, (7, 9)), (16, 16, (16, 16)), (8, 8, (16, 16)), (1, 1, (1, 1))]
+
+
+@pytest.mark.parametrize("using_octree", [1, 0], ids=["array", "svo"])
+@pytest.mark.parametrize("make", [scenes.floor_pillars, scenes.mirror_wall], ids=["floor_pillars", "mirror_wall"])
+@pytest.mark.parametrize("shape", ATLAS_SHAPES, ids=[f"{w}x{h}-tile{t[0]}x{t[1]}" for w, h, t in ATLAS_SHAPES])
+def test_atlas_and_tile_shapes_other_than_the_apps(shape, make, using_octree):
+    """create_texture_atlas (src/CLCaster.cpp:208-222) takes any texture and tile size; the kernel's texel arithmetic
+    (:652-656, :684-688: uv * (atlas_dim / tile_dim) + tile * (atlas_dim / tile_dim), integer division) only lands
+    inside tile (5,0) / (3,4) for the app's 256 / 16.  Whatever it lands on -- other tiles, the clamp at the atlas edge
+    -- must be the same texel in the HIP path and the oracle: the material-5 tile colours the frame
+    (floor_pillars), the mirror tile is fetched twice per pixel and only counted (mirror_wall: a reflected ray starts
+    inside the mirror voxel and strikes it again, :700-702, so the reference's mirrors come out black)."""
+    from test_parity_gpu import assert_same
+    aw, ah, tile = shape
+    atlas = vrc.synthetic_atlas(aw, ah)
+    s = make()
+    dim, w, h = s["dim"], 160, 120
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000).attach_materials_from_grid(s["grid"])
+    c = vrc.CLCaster()
+    assert c.init(0) and c.assign_octree(o) and c.assign_map(s["grid"], (dim, dim, dim))
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = s["lights"]
+    assert c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c.add_to_settings_buffer("using_octree", "OCTENABLED", using_octree)
+    assert c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", 3 * dim)
+    cd, cp = np.array(s["cam_dir"], dtype=np.float32), np.array(s["cam_pos"], dtype=np.float32)
+    assert c.assign_camera(cd, cp) and c.create_viewport(w, h) and c.assign_lights(li)
+    assert c.create_texture_atlas(atlas, tile)
+    if tile[0] > aw or tile[1] > ah:                     # atlas_dim / tile_dim == 0: refused by validate(), not rendered
+        assert not c.validate() and "tile larger than atlas" in c.last_error()
+        return
+    assert c.validate() and c.compute(), c.last_error()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=li, atlas=atlas,
+                                    tile_dim=tile, descriptors=o.descriptor_buffer, root_index=o.root_index,
+                                    octree_dim=dim, using_octree=using_octree, grid=s["grid"], max_distance=3 * dim,
+                                    attachment_lookup=o.attachment_lookup, attachments=o.attachment_buffer)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+    assert octr["n_tex"] > 0 and (ohits[..., 3] == (6 if make is scenes.mirror_wall else 5)).any()
