@@ -126,7 +126,8 @@ int vrc_assign_lights(vrc_caster *h, const float *packed, const int32_t *light_c
  *   using_octree       (OCTENABLED)        0 => occupancy from the SVO, != 0 => dense map
  *   octree_root_index  (OCTREE_ROOT_INDEX) set by vrc_assign_octree
  * extensions (defaults reproduce the reference):
- *   max_distance (20)  shadow_rays (1)  light_count (1, see vrc_assign_lights)
+ *   max_distance (20: the :325/:357 step cap; |value| <= 2^30, the counter is the reference's int)
+ *   shadow_rays (1)  light_count (1, see vrc_assign_lights)
  *   octree_bias (1: the :353-354 term as in the reference; 0: without it)
  *   hit_records (1: the 8 x int32 record per pixel behind vrc_read_hits; 0: none -- the reference has none)
  *   stepping_mode (0: exact per-voxel DDA, bit-identical to the array branch; 1: node-exit jumps, DESIGN.md "mode B")

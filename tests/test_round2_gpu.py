@@ -375,7 +375,7 @@ def test_live_settings_are_rechecked_by_every_compute(atlas):
     good = c.read_image()
     for name, value, word in [("octree_dimensions", 3, "power of two"), ("octree_dimensions", 1 << 30, "power of two"),
                               ("octree_root_index", 10 ** 9, "out of range"), ("using_octree", 1, "dense map"),
-                              ("stepping_mode", 7, "stepping_mode")]:
+                              ("stepping_mode", 7, "stepping_mode"), ("max_distance", 1 << 31, "max_distance")]:
         old = c.get_setting(name)
         if old is None:
             assert c.add_to_settings_buffer(name, name.upper(), value)

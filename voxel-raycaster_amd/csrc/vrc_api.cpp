@@ -789,7 +789,12 @@ int compute_async_one(vrc_caster *h) {
         }
         light_reach += std::sqrt(far2) + 2.0;
     }
-    p.max_distance = (int32_t)setting_or(h, "max_distance", 20);
+    {   // the kernel's step counter is the reference's int (:325): a cap beyond 2^30 would overflow it on the way
+        const int64_t md = setting_or(h, "max_distance", 20);
+        if (md > (int64_t)1 << 30 || md < -((int64_t)1 << 30))
+            return fail(h, VRC_ERR_INVALID_ARGUMENT, "compute: max_distance %lld is outside [-2^30, 2^30]", (long long)md);
+        p.max_distance = (int32_t)md;
+    }
     p.shadow_rays = (int32_t)setting_or(h, "shadow_rays", 1);
     // wave scheduling knobs of the SVO kernel; they never change results
     p.burst_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "burst_steps", vrc::kDefaultBurstSteps)));
