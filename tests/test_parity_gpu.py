@@ -36,7 +36,7 @@ def make_caster(octree, dim, using_octree, cam_dir, cam_pos, lights, atlas, w, h
         assert c.assign_map(grid, (dim, dim, dim))
     cd, cp = np.array(cam_dir, dtype=np.float32), np.array(cam_pos, dtype=np.float32)
     assert c.assign_camera(cd, cp)
-    assert c.create_viewport(w, h, 0.0, 0.0)
+    assert c.create_viewport(w, h, 0.0, 0.0), c.last_error()
     li = np.zeros((8, 10), dtype=np.float32)
     li[: np.asarray(lights).reshape(-1, 10).shape[0]] = np.asarray(lights).reshape(-1, 10)
     assert c.assign_lights(li)

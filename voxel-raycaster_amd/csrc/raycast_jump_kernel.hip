@@ -327,6 +327,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
 }
 
 hipError_t launch_raycast_jump(const RaycastParams &p, hipStream_t stream) {
+    (void)hipGetLastError();                 // an error an earlier call left behind is not this launch's
     const int nblocks = p.blocks_x * p.local_tile_rows;
     if (nblocks <= 0) return hipSuccess;
     const int levels = p.log2_dim > 2 ? p.log2_dim - 2 : 1;     // >= the counter partials that reuse the memory

@@ -626,12 +626,14 @@ __global__ void pack_rgba8_kernel(const float4 *__restrict__ image, uchar4 *__re
 }
 
 hipError_t launch_fill_image(float *image, size_t n_pixels, hipStream_t stream) {
+    (void)hipGetLastError();                 // an error an earlier call left behind is not this launch's
     if (!n_pixels) return hipSuccess;
     hipLaunchKernelGGL(fill_image_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<float4 *>(image), n_pixels);
     return hipGetLastError();
 }
 
 hipError_t launch_pack_rgba8(const float *image, uint8_t *out, size_t n_pixels, hipStream_t stream) {
+    (void)hipGetLastError();                 // an error an earlier call left behind is not this launch's
     if (!n_pixels) return hipSuccess;
     hipLaunchKernelGGL(pack_rgba8_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream,
                        reinterpret_cast<const float4 *>(image), reinterpret_cast<uchar4 *>(out), n_pixels);
@@ -639,6 +641,7 @@ hipError_t launch_pack_rgba8(const float *image, uint8_t *out, size_t n_pixels, 
 }
 
 hipError_t launch_frame_setup(const RaycastParams &p, hipStream_t stream) {
+    (void)hipGetLastError();                 // an error an earlier call left behind is not this launch's
     hipLaunchKernelGGL(frame_setup_kernel, dim3(1), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
@@ -646,6 +649,7 @@ hipError_t launch_frame_setup(const RaycastParams &p, hipStream_t stream) {
 hipError_t launch_raycast_jump(const RaycastParams &p, hipStream_t stream);   // raycast_jump_kernel.hip
 
 hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
+    (void)hipGetLastError();                 // an error an earlier call left behind is not this launch's
     const int nblocks = p.blocks_x * p.local_tile_rows;
     if (nblocks <= 0) return hipSuccess;
     if (p.svo && p.stepping_mode == 1) return launch_raycast_jump(p, stream);
@@ -672,6 +676,7 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
 
 hipError_t launch_reduce_counters(const unsigned long long *partials, int nblocks, unsigned long long *out,
                                   hipStream_t stream) {
+    (void)hipGetLastError();                 // an error an earlier call left behind is not this launch's
     hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, stream, partials, nblocks, out);
     return hipGetLastError();
 }

@@ -338,6 +338,7 @@ int build_shell_terrain_device(hipStream_t stream, uint32_t depth, uint64_t seed
     int rc = VRC_OK;
     vrc_build_info bi;
     memset(&bi, 0, sizeof(bi));
+    (void)hipGetLastError();                 // the launch checks below must not pick up an error an earlier call left behind
     const int64_t dim = 1LL << depth;
     const int kb = std::min<int>(kBrickLog2, (int)depth);
     const int64_t cells = dim >> kb;

@@ -94,9 +94,11 @@ int fail(vrc_caster *h, int code, const char *fmt, ...) {
 #define HIP_TRY(h, call)                                                                          \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
+        if (e_ != hipSuccess) {                                                                   \
+            (void)hipGetLastError();      /* reported here: not left behind for a later launch check */ \
             return fail(h, e_ == hipErrorOutOfMemory ? VRC_ERR_OUT_OF_MEMORY : VRC_ERR_DEVICE,    \
                         "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                         \
     } while (0)
 
 // replicate a call on every other rank of a group; the first failure is reported through rank 0
@@ -947,11 +949,15 @@ int vrc_device_image(vrc_caster *h, void **dev_ptr, size_t *n_bytes) {
 
 int vrc_pin_host_buffer(void *p, size_t bytes) {
     if (!p || !bytes) return VRC_ERR_INVALID_ARGUMENT;
-    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? VRC_OK : VRC_ERR_DEVICE;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) return VRC_OK;
+    (void)hipGetLastError();
+    return VRC_ERR_DEVICE;
 }
 int vrc_unpin_host_buffer(void *p) {
     if (!p) return VRC_ERR_INVALID_ARGUMENT;
-    return hipHostUnregister(p) == hipSuccess ? VRC_OK : VRC_ERR_DEVICE;
+    if (hipHostUnregister(p) == hipSuccess) return VRC_OK;
+    (void)hipGetLastError();                 // reported through the return code, not left behind for the next launch
+    return VRC_ERR_DEVICE;
 }
 
 int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out) {
