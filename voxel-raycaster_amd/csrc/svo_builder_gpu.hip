@@ -326,6 +326,7 @@ double now_s() {
         hipError_t e_ = (call);                                                                               \
         if (e_ != hipSuccess) {                                                                               \
             error = std::string(#call) + " failed: " + hipGetErrorString(e_);                                 \
+            (void)hipGetLastError();              /* reported here, not left behind */                        \
             rc = e_ == hipErrorOutOfMemory ? VRC_ERR_OUT_OF_MEMORY : VRC_ERR_DEVICE;                          \
             goto cleanup;                                                                                     \
         }                                                                                                     \
