@@ -282,6 +282,9 @@ def main():
     import voxel_raycaster_amd  # noqa: F401  (fails loudly if the HIP library is missing)
 
     sc, tree_file = shared_scene(args.depth, rank, world, os.environ.get("MASTER_PORT", "0"))
+    if tree_file and rank == 0:                                # /dev/shm is memory: the file must not outlive a failed run
+        import atexit
+        atexit.register(lambda: os.path.exists(tree_file) and os.remove(tree_file))
     W, H = args.width, args.height
     full_h = H * world
     table = None if world == 1 else supersampled_table(W, H, world)
@@ -293,7 +296,7 @@ def main():
     del table
     if world > 1:
         barrier(local_rank)
-        if rank == 0:
+        if rank == 0 and os.path.exists(tree_file):
             os.remove(tree_file)
 
     # set-up, not measurement: a fresh process finds the GPU at its idle clocks, and a 3 ms kernel needs a few dozen
