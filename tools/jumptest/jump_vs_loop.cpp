@@ -1,20 +1,26 @@
-// Host check of exact_jump.hpp: random ray states, jump-driven stepping vs the plain float loop.
+// Host check of exact_jump.hpp: random ray states, jump-driven stepping vs the plain float loop
+// (kernels/ray_caster_kernel.cl:558-560).  The plain loop records the state after every iteration; the jump-driven run
+// must land exactly on a recorded state after every single jump (intersection_t bits, countdowns, iteration count) and
+// agree on the face mask of the leaving iteration and on the exit / cap verdict.
 // g++ -O2 -ffp-contract=off -std=c++17 -o jump_vs_loop jump_vs_loop.cpp ; ./jump_vs_loop [cases] [seed]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <vector>
 
 #include "../../voxel-raycaster_amd/csrc/exact_jump.hpp"
 
 using namespace vrc;
 
 struct State { float t[3], d[3]; int n[3]; };
-struct Outcome { float t[3]; int n[3]; int iters; bool left_node, capped; int f[3]; };
+struct Snap { float t[3]; int n[3]; };
+struct Outcome { int iters; bool left_node, capped; int f[3]; };
 
-static Outcome plain(State s, int left) {
+static Outcome plain(State s, int left, std::vector<Snap> &trace) {
     Outcome o{};
+    trace.clear();
     int it = 0;
     for (;;) {
         float m = fminf(fminf(s.t[0], s.t[1]), s.t[2]);
@@ -22,31 +28,44 @@ static Outcome plain(State s, int left) {
         for (int a = 0; a < 3; a++) { f[a] = s.t[a] <= m; }
         for (int a = 0; a < 3; a++) { s.t[a] = s.t[a] + s.d[a] * (float)f[a]; s.n[a] -= f[a]; }
         it++;
+        Snap sn; memcpy(sn.t, s.t, sizeof(sn.t)); memcpy(sn.n, s.n, sizeof(sn.n));
+        trace.push_back(sn);
         if (s.n[0] == 0 || s.n[1] == 0 || s.n[2] == 0) { o.left_node = true; memcpy(o.f, f, sizeof(f)); break; }
         if (it == left) { o.capped = true; break; }
     }
-    memcpy(o.t, s.t, sizeof(o.t)); memcpy(o.n, s.n, sizeof(o.n)); o.iters = it;
+    o.iters = it;
     return o;
 }
 
-static long g_jumps = 0, g_jump_iters = 0, g_plain_iters = 0;
+static long g_jumps = 0, g_jump_iters = 0, g_plain_iters = 0, g_fills = 0, g_partial = 0;
 
-static Outcome jumped(State s, int left, int min_run) {
-    Outcome o{};
-    JumpCache cache; jump_cache_reset(cache);
+// returns false on a mismatch against the trace
+static bool jumped(State s, int left, int mix, const std::vector<Snap> &trace, Outcome &o, std::mt19937_64 &rng) {
+    o = Outcome{};
+    uint32_t tab[kJumpTableDwords];
+    memset(tab, 0xff, sizeof(tab));                // stale bytes everywhere: only rows marked in `rows` may be read
+    uint32_t rows = 0;
+    // now and then the table is not kept up (rows missing or cut off): those pairs must then be solved on the spot
+    const int sloppy = (int)(rng() % 8);
     int it = 0;
     for (;;) {
-        int mn = s.n[0] < s.n[1] ? s.n[0] : s.n[1]; mn = mn < s.n[2] ? mn : s.n[2];
-        if (mn >= min_run) {
-            JumpResult r = try_jump(s.t[0], s.t[1], s.t[2], s.d[0], s.d[1], s.d[2], s.n[0], s.n[1], s.n[2], left - it, cache);
-            if (r.iterations > 0) {
-                g_jumps++; g_jump_iters += r.iterations;
-                it += r.iterations;
-                if (r.capped) { o.capped = true; break; }
-                if (r.left_node) { o.left_node = true; o.f[0] = r.fx; o.f[1] = r.fy; o.f[2] = r.fz; break; }
-                if (it == left) { o.capped = true; break; }
-                continue;
-            }
+        if (mix == 0 || (rng() % (unsigned)mix) != 0) {
+            uint32_t fills = 0;
+            if (sloppy != 0) jump_rows_build(true, true, rows, s.t[0], s.t[1], s.t[2], s.d[0], s.d[1], s.d[2], tab, 1, fills);
+            else memset(tab, 0, sizeof(tab));      // "no entry" everywhere
+            g_fills += fills;
+            JumpOut r = stretch_jump(s.t[0], s.t[1], s.t[2], s.d[0], s.d[1], s.d[2], s.n[0], s.n[1], s.n[2], left - it, tab, 1);
+            if (r.iterations < 1) return false;
+            g_jumps++; g_jump_iters += r.iterations;
+            it += r.iterations;
+            if (r.capped) { o.capped = true; break; }
+            if (it > (int)trace.size()) return false;
+            const Snap &sn = trace[it - 1];
+            if (memcmp(sn.t, s.t, sizeof(sn.t)) != 0 || memcmp(sn.n, s.n, sizeof(sn.n)) != 0) return false;
+            if (r.left_node) { o.left_node = true; o.f[0] = (int)r.fx; o.f[1] = (int)r.fy; o.f[2] = (int)r.fz; break; }
+            g_partial++;
+            if (it == left) { o.capped = true; break; }
+            continue;
         }
         float m = fminf(fminf(s.t[0], s.t[1]), s.t[2]);
         int f[3];
@@ -56,8 +75,8 @@ static Outcome jumped(State s, int left, int min_run) {
         if (s.n[0] == 0 || s.n[1] == 0 || s.n[2] == 0) { o.left_node = true; memcpy(o.f, f, sizeof(f)); break; }
         if (it == left) { o.capped = true; break; }
     }
-    memcpy(o.t, s.t, sizeof(o.t)); memcpy(o.n, s.n, sizeof(o.n)); o.iters = it;
-    return o;
+    o.iters = it;
+    return true;
 }
 
 int main(int argc, char **argv) {
@@ -66,45 +85,61 @@ int main(int argc, char **argv) {
     std::mt19937_64 rng(seed);
     std::uniform_real_distribution<double> U(0.0, 1.0);
     long bad = 0;
+    std::vector<Snap> trace;
     for (long c = 0; c < cases; c++) {
         State s;
         double dir[3];
-        const int kind = (int)(rng() % 10);
+        const int kind = (int)(rng() % 14);
         for (int a = 0; a < 3; a++) dir[a] = U(rng) * 2 - 1;
         if (kind == 0) dir[1] = dir[0];                                  // every step ties x/y
         if (kind == 1) { dir[1] = dir[0]; dir[2] = dir[0]; }             // triple ties
         if (kind == 2) dir[1] = dir[0] * 0.5;                            // every other step ties
         if (kind == 3) { dir[0] = 0.5; dir[1] = 0.25; dir[2] = 0.125; }  // powers of two
         if (kind == 4) dir[2] = dir[0] * 3.0;
+        if (kind == 5) { dir[1] = dir[0] * 0.75; dir[2] = dir[0] * 0.375; }   // small rational ratios: many common values
+        if (kind == 6) dir[(int)(rng() % 3)] *= 1e-3;                    // one slow axis (huge delta_t: frozen below delta_t)
+        if (kind == 7) { dir[0] = 1.0; dir[1] = 1.0 / 3.0; dir[2] = 1.0 / 5.0; }
         double len = std::sqrt(dir[0]*dir[0] + dir[1]*dir[1] + dir[2]*dir[2]);
+        if (kind == 8) len = 1.0;                                        // host-supplied ray tables need not be normalised
         for (int a = 0; a < 3; a++) {
             float rd = (float)(dir[a] / len);
             if (rd == 0.0f) rd = 1e-3f;
             s.d[a] = fabsf(1.0f / rd);
+            if (kind == 9) s.d[a] = (float)(1 + rng() % 6) * ((rng() & 1) ? 1.0f : 1.5f);   // short mantissas: half-way cases, gcds
             float frac = (kind <= 3 && (rng() & 1)) ? 0.5f : (float)U(rng);
             s.t[a] = s.d[a] * frac;
             if ((rng() % 50) == 0) s.t[a] -= (float)(rng() % 7);         // negative starts (octree bias)
+            if ((rng() % 200) == 0) s.t[a] = 0.0f;
         }
-        // warm up: K plain iterations
-        int K = (int)std::exp(U(rng) * std::log(6000.0));
-        for (int k = 0; k < K; k++) {
+        // warm up: plain iterations so that t sits in a random binade up to ~2^18 (the depth-16 scenes reach 2^17)
+        const double target = std::exp(U(rng) * std::log(kind == 10 ? 3.0e5 : 3.0e4));
+        for (int k = 0; k < 400000; k++) {
             float m = fminf(fminf(s.t[0], s.t[1]), s.t[2]);
+            if (m >= target) break;
             for (int a = 0; a < 3; a++) if (s.t[a] <= m) s.t[a] = s.t[a] + s.d[a];
         }
-        for (int a = 0; a < 3; a++) s.n[a] = 1 + (int)std::exp(U(rng) * std::log(2048.0));
-        int left = (rng() % 4 == 0) ? 1 + (int)(rng() % 600) : 100000;
-        int min_run = (rng() & 1) ? 1 : 8;
-        Outcome p = plain(s, left), j = jumped(s, left, min_run);
-        bool same = p.iters == j.iters && p.left_node == j.left_node && p.capped == j.capped;
-        if (same && p.left_node) same = memcmp(p.f, j.f, sizeof(p.f)) == 0 && memcmp(p.t, j.t, sizeof(p.t)) == 0 && memcmp(p.n, j.n, sizeof(p.n)) == 0;
+        if (kind == 11) {                                                // start right below a binade end
+            int a = (int)(rng() % 3);
+            if (s.t[a] > 1.0f) { uint32_t b = f2u(s.t[a]); b |= 0x7fff00u; s.t[a] = u2f(b); }
+        }
+        if (kind == 12) { int a = (int)(rng() % 3), b = (a + 1) % 3; s.t[b] = s.t[a]; }   // an exact tie to start with
+        const int nmax = (kind == 13) ? 40000 : 3000;
+        for (int a = 0; a < 3; a++) s.n[a] = 1 + (int)std::exp(U(rng) * std::log((double)nmax));
+        int left = (rng() % 4 == 0) ? 1 + (int)(rng() % 2000) : 1000000;
+        int mix = (rng() % 3 == 0) ? 0 : 2 + (int)(rng() % 6);           // 0: jumps only; k: a plain step with probability 1/k
+        Outcome p = plain(s, left, trace), j;
+        bool same = jumped(s, left, mix, trace, j, rng);
+        same = same && p.iters == j.iters && p.left_node == j.left_node && p.capped == j.capped;
+        if (same && p.left_node) same = memcmp(p.f, j.f, sizeof(p.f)) == 0;
         if (!same) {
             if (bad < 10)
-                printf("MISMATCH case %ld kind %d: t=(%a,%a,%a) d=(%a,%a,%a) n=(%d,%d,%d) left=%d | plain it=%d exit=%d cap=%d | jump it=%d exit=%d cap=%d\n",
-                       c, kind, s.t[0], s.t[1], s.t[2], s.d[0], s.d[1], s.d[2], s.n[0], s.n[1], s.n[2], left, p.iters, p.left_node, p.capped,
+                printf("MISMATCH case %ld kind %d: t=(%a,%a,%a) d=(%a,%a,%a) n=(%d,%d,%d) left=%d mix=%d | plain it=%d exit=%d cap=%d | jump it=%d exit=%d cap=%d\n",
+                       c, kind, s.t[0], s.t[1], s.t[2], s.d[0], s.d[1], s.d[2], s.n[0], s.n[1], s.n[2], left, mix, p.iters, p.left_node, p.capped,
                        j.iters, j.left_node, j.capped);
             bad++;
         }
     }
-    printf("cases %ld mismatches %ld | jumps %ld covering %ld iterations, %ld plain iterations\n", cases, bad, g_jumps, g_jump_iters, g_plain_iters);
+    printf("cases %ld mismatches %ld | jumps %ld covering %ld iterations, %ld plain iterations, %ld partial jumps, %ld pair solves\n",
+           cases, bad, g_jumps, g_jump_iters, g_plain_iters, g_partial, g_fills);
     return bad ? 1 : 0;
 }

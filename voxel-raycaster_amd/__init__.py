@@ -16,7 +16,9 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvrc.so")
+# VRC_LIB_PATH: load another build of the same library (A/B variants and the -DVRC_SCHED_STATS profiling build of tools/)
+# instead of copying it over the product file
+LIB_PATH = os.environ.get("VRC_LIB_PATH") or os.path.join(_HERE, "libvrc.so")
 
 
 class VrcError(RuntimeError):

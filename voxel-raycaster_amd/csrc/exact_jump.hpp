@@ -2,44 +2,58 @@
 //
 // The reference advances a ray with (kernels/ray_caster_kernel.cl:558-560)
 //     face_mask = (t.xyz <= min(t.yzx, t.zxy));   t += delta_t * face_mask;   voxel += step * face_mask;
-// once per loop iteration, and the iteration count feeds the fog factor (:716) and the shadow-ray cap
-// (:667).  Bit-exact parity therefore needs the k-fold float accumulation of t AND the exact number of
-// iterations, including iterations in which two or three axes tie and step together.
+// once per loop iteration, and the iteration count feeds the fog factor (:716), the out-of-map colour (:565) and the
+// shadow-ray cap (:667).  Bit-exact parity therefore needs the k-fold float accumulation of t AND the exact number of
+// iterations, including iterations in which two or three axes tie and step together.  This is what the reference's own
+// unfinished octree branch was reaching for at :525-540 (intersection_t += delta_t * jump_power * fabs(face_mask)).
 //
-// Inside one binade [2^e, 2^(e+1)) a float t is an integer mantissa M times u = 2^(e-23), and
-// RNE(t + d) = t + inc*u with a constant integer inc (d rounded to a multiple of u; when d sits exactly
-// half-way the increment is the even neighbour once M is even).  So each axis is an exact arithmetic
-// progression of integers until it leaves its binade, and
+// Inside one binade [2^e, 2^(e+1)) a float t is an integer mantissa M times u = 2^(e-23), and RNE(t + d) = t + inc*u
+// with a constant integer inc (d rounded to a multiple of u; when d sits exactly half-way the increment is the even
+// neighbour once M is even).  So, until it leaves its binade, each axis is an exact arithmetic progression of integers
+// -- of the float's BIT PATTERN even: bits(v_k) = bits(t) + k*inc -- and
 //   * the value after k steps,
-//   * the number of steps with value <= X,
-//   * the number of EQUAL values of two axes (a linear congruence, solved with one modular inverse
-//     per axis pair and binade)
-// are all closed forms.  try_jump() consumes every iteration up to the one that leaves the node -- or up to
-// (just before) the first binade boundary of any axis, whichever comes first -- and reports how many loop
-// iterations that was.  Anything outside the simple regime (t <= 0, t < d, unsettled half-way case) is
-// left to the ordinary step loop, which is always correct; so is any jump whose integer estimates fail
-// their own validity check.
+//   * the number of steps with value <= X (one integer division),
+//   * the number of EQUAL values of two axes (a linear congruence: one extended-Euclid run per axis pair, binade and
+//     ray direction, kept in a per-ray table)
+// are closed forms.  stretch_jump() consumes every iteration up to and including the one that leaves the node -- or up
+// to the last value an axis has below its binade end, whichever comes first -- and reports how many loop iterations that
+// was.  It ALWAYS makes progress (>= 1 iteration): an axis outside the simple regime (t <= 0 or tiny, t not above
+// delta_t's binade, unsettled half-way case, increment below 64 ulps) is FROZEN, i.e. a one-element progression whose
+// single step is taken with one real float add and which bounds the stretch.  A stretch that ends early is simply
+// continued by the next call (or by the ordinary step loop, which is always correct).
 //
-// Host+device header: tools/jumptest/jump_vs_loop.cpp drives the host build against the plain loop on
-// millions of random states (tests/test_exact_jump.py); raycast_kernel.hip uses the device build.
+// The Euclid runs are the expensive part (a loop of 15-25 dependent divisions) and a ray needs one per axis pair and
+// binade.  The increments depend on (delta_t, binade) only, so the runs are shared by the wave: when the first lane needs
+// binade e, the three pairs of EVERY lane whose ray keeps its direction are solved for e in one loop (jump_rows_build) and
+// kept in a per-ray table -- the rays of a tile reach a binade within a few rounds of each other.
+//
+// Host+device header: tools/jumptest/jump_vs_loop.cpp drives the host build against the plain loop on millions of
+// random states (tests/test_exact_jump.py); raycast_kernel.hip uses the device build.
 #pragma once
 
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define VRC_HD __host__ __device__ __forceinline__
-#define VRC_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define VRC_HD inline
-#define VRC_HD_NOINLINE inline
+#endif
+// wave votes: the warm and cold sections run only when a lane needs them; the host build is a "wave" of one lane
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VRC_BALLOT(c) __ballot(c)
+#define VRC_WAVE_ANY(c) (__ballot(c) != 0ULL)
+#define VRC_FIRST_LANE_VALUE(v, mask) __builtin_amdgcn_readlane((v), __ffsll((long long)(mask)) - 1)
+#else
+#define VRC_BALLOT(c) ((c) ? 1ULL : 0ULL)
+#define VRC_WAVE_ANY(c) (c)
+#define VRC_FIRST_LANE_VALUE(v, mask) (v)
 #endif
 
 namespace vrc {
 
 VRC_HD uint32_t f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
 VRC_HD float u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
-// float with biased exponent e and 24-bit mantissa M (hidden bit included)
-VRC_HD float mk_float(int32_t e, int32_t M) { return u2f(((uint32_t)e << 23) | ((uint32_t)M & 0x7fffffu)); }
 
 VRC_HD float fast_rcp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -53,268 +67,362 @@ VRC_HD float fast_rcp(float x) {
     return 1.0f / x;
 #endif
 }
+// a * b for 0 <= a, b < 2^24 (v_mul_u32_u24: full rate; v_mul_lo_u32 is not)
+VRC_HD int32_t mul24(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int32_t)__umul24((unsigned)a, (unsigned)b);
+#else
+    return (int32_t)((uint32_t)a * (uint32_t)b);
+#endif
+}
 
-// floor(a / b), a mod b for 0 <= a < 2^25, 1 <= b < 2^24.  Reciprocal estimate, then the exact integer
-// remainder corrected by up to two units each way, branch-free.  `ok` is cleared if that was not enough
-// (tiny b with huge quotient): the caller then refuses the jump.
-VRC_HD int32_t idivmod(int32_t a, int32_t b, int32_t &rem, bool &ok) {
-    int32_t q = (int32_t)((float)a * fast_rcp((float)b));
+// reciprocal of an integer 1 <= b < 2^24 to ~2^-44 relative: hardware estimate + one Newton step in fp64
+VRC_HD double recip_d(int32_t b) {
+    const double bd = (double)b, r0 = (double)fast_rcp((float)b);
+    return __builtin_fma(r0, __builtin_fma(-bd, r0, 1.0), r0);
+}
+// floor(a / b) and a - floor(a/b) * b for |a| < 2^31, 1 <= b < 2^24, |a / b| < 2^26; rb = recip_d(b).  Exact: the
+// estimate is within 2^-18 of the quotient, so the floor is at most one off, and the remainder check settles it.
+VRC_HD int32_t floordiv(int32_t a, int32_t b, double rb, int32_t &rem) {
+    int32_t q = (int32_t)__builtin_floor((double)a * rb);
     int32_t r = a - q * b;
-    int32_t adj = (r < 0) ? -1 : 0;  q += adj; r -= adj * b;
-    adj = (r < 0) ? -1 : 0;          q += adj; r -= adj * b;
-    adj = (r >= b) ? 1 : 0;          q += adj; r -= adj * b;
-    adj = (r >= b) ? 1 : 0;          q += adj; r -= adj * b;
-    ok = ok && (r >= 0) && (r < b);
+    const int32_t dn = (r < 0) ? 1 : 0;
+    q -= dn; r += dn ? b : 0;
+    const int32_t up = (r >= b) ? 1 : 0;
+    q += up; r -= up ? b : 0;
     rem = r;
     return q;
 }
-// exact variants with unbounded correction (cold paths only)
-VRC_HD int32_t idivmod_loop(int32_t a, int32_t b, int32_t &rem) {
+// floor(a / b) for 0 <= a < 2^24, 64 <= b < 2^24 (quotient < 2^18: the float estimate is within one)
+VRC_HD int32_t floordiv_small(int32_t a, int32_t b) {
     int32_t q = (int32_t)((float)a * fast_rcp((float)b));
-    int32_t r = a - q * b;
-    while (r < 0) { q--; r += b; }
-    while (r >= b) { q++; r -= b; }
-    rem = r;
+    const int32_t r = a - mul24(q, b);
+    q -= (r < 0) ? 1 : 0;
+    q += (r >= b) ? 1 : 0;
     return q;
 }
-VRC_HD int32_t idiv_loop(int32_t a, int32_t b) { int32_t r; return idivmod_loop(a, b, r); }
-VRC_HD int32_t imod_loop(int32_t a, int32_t b) {                 // |a| < 2^25, result in [0, b)
-    int32_t r;
-    if (a >= 0) { idivmod_loop(a, b, r); return r; }
-    idivmod_loop(-a, b, r);
-    return r ? b - r : 0;
-}
-
-// (x * y) mod m for 0 <= x, y < m < 2^24: the 48-bit product is exact in fp64; the quotient is estimated in
-// fp32 and the remainder corrected by up to two multiples of m each way
-VRC_HD int32_t mulmod(int32_t x, int32_t y, int32_t m, bool &ok) {
-    const double prod = (double)x * (double)y;
-    const double dm = (double)m;
-    const double q = (double)__builtin_truncf((float)prod * fast_rcp((float)m));
+// (c * s) mod m in [0, m) for |c| < 2^24, 0 <= s < m < 2^24: the 48-bit product is exact in fp64; rm = recip_d(m)
+VRC_HD int32_t mulmod(int32_t c, int32_t s, int32_t m, double rm) {
+    const double prod = (double)c * (double)s, dm = (double)m;
+    const double q = __builtin_floor(prod * rm);                  // |true quotient| < 2^24: within 2^-20 of it
     double r = __builtin_fma(-q, dm, prod);                       // exact
     r += (r < 0.0) ? dm : 0.0;
-    r += (r < 0.0) ? dm : 0.0;
     r -= (r >= dm) ? dm : 0.0;
-    r -= (r >= dm) ? dm : 0.0;
-    ok = ok && (r >= 0.0) && (r < dm);
     return (int32_t)r;
 }
 
-struct AxisProg {          // one axis inside its current binade
-    int32_t M;             // mantissa of t in units of u (2^23 <= M < 2^24)
-    int32_t inc;           // exact increment per step, in units of u
-    int32_t e;             // biased exponent field of t
-    int32_t room;          // LOWER BOUND on the steps j for which M + j*inc stays below 2^24
-    bool ok;               // axis is in the simple regime
-};
+// ---------------------------------------------------------------------------------------------------------------
+// The increment of one axis in the binade with exponent field e: bits(RNE(2^(e-127) + d)) - bits(2^(e-127)), i.e. the
+// FPU's own rounding of d to a multiple of the binade's ulp, started from an even mantissa.  It depends on (d, e) only.
+// `halfway`: d lies exactly half-way between two multiples (then the progression needs an even mantissa to start from).
+// Valid for jump_binade_ok(e, d).
+// ---------------------------------------------------------------------------------------------------------------
+VRC_HD bool jump_binade_ok(int32_t e, float d) {
+    const int32_t sh = e - (int32_t)(f2u(d) >> 23);
+    // 25 <= e: half an ulp is a normal float; sh >= 1: t + d can stay inside the binade at all; sh <= 17 keeps the
+    // increment at 64 ulps or more (quotients stay small enough for float estimates)
+    return (uint32_t)(e - 25) <= (uint32_t)(253 - 25) && (uint32_t)(sh - 1) <= 16u;
+}
+VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
+    const float P = u2f((uint32_t)e << 23);
+    const float S = P + d;                                        // one real rounding; < 2P or exactly 2P
+    const float err = d - (S - P);                                // both subtractions are exact
+    halfway = __builtin_fabsf(err) == u2f((uint32_t)(e - 24) << 23);
+    return (int32_t)(f2u(S) - ((uint32_t)e << 23));
+}
 
-VRC_HD AxisProg make_prog(float t, float d) {
-    AxisProg p;
-    const uint32_t tb = f2u(t), db = f2u(d);
-    p.e = (int32_t)(tb >> 23);                                    // sign bit set => e >= 256 => rejected below
-    const int32_t ed = (int32_t)(db >> 23);
-    p.M = (int32_t)((tb & 0x7fffffu) | 0x800000u);
-    const int32_t Md = (int32_t)((db & 0x7fffffu) | 0x800000u);
-    const int32_t sh = p.e - ed;
-    p.ok = (p.e >= 1 && p.e <= 254 && ed >= 1 && ed <= 254 && sh >= 0 && sh <= 23);
-    const int32_t shc = p.ok ? sh : 0;
-    const int32_t D = Md >> shc, rem = Md & ((1 << shc) - 1), half = (shc > 0) ? (1 << (shc - 1)) : 0;
-    const bool halfway = shc > 0 && rem == half;                  // d exactly half-way between two multiples of u
-    p.ok = p.ok && !(halfway && (p.M & 1));                       // ... needs an even M (one ordinary step settles it)
-    p.inc = halfway ? D + (D & 1) : D + ((shc > 0 && rem > half) ? 1 : 0);
-    // conservative estimate of floor((2^24 - 1 - M) / inc): never too large, at most a couple too small
-    const float est = (float)(0xffffff - p.M) * fast_rcp((float)p.inc) * 0.999999f;
-    const int32_t rl = (int32_t)est - 1;
-    p.room = rl > 0 ? rl : 0;
+// ---------------------------------------------------------------------------------------------------------------
+// per-ray table of the Euclid runs (jump_rows_build): one dword per (binade row, axis pair),
+//   row = e - kJumpFirstBinade (0 <= row < kJumpBinades), pairs xy, xz, yz:   tab[(3 * row + pair) * stride]
+//   bits 0-23  s: s * inc_a == g (mod inc_b), 0 <= s < inc_b        bits 24-31  g = gcd(inc_a, inc_b)
+//   g == 255: the gcd is 255 or more (the pair is solved afresh when it is needed: rare);  whole dword 0: no entry
+// The increments depend on (delta_t, binade) only.  In HBM (RaycastParams::jump_cache), one table per lane, interleaved
+// over the 64 lanes of a wave (stride 64) so that a row is one coalesced 256-byte line.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef VRC_JUMP_FIRST_LOG2
+#define VRC_JUMP_FIRST_LOG2 7
+#endif
+constexpr int kJumpFirstBinade = 127 + VRC_JUMP_FIRST_LOG2;   // no table below t = 128: a binade of fewer voxels than a Euclid run costs
+constexpr int kJumpBinades = 12;              // t < 2^19
+constexpr int kJumpTableDwords = 3 * kJumpBinades;
+
+// s and g with s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib; 1 <= ia, ib < 2^24 -- for the three axis pairs at
+// once (three independent chains per loop trip).  Extended Euclid on exact integers held in floats.  The quotient
+// estimate is rounded DOWN (never above the true floor): a short quotient only splits one Euclid step into two, so
+// remainders stay non-negative, the cofactors alternate in sign and stay below ib, and every fma is exact.
+// Branch-free body; the loop runs while any chain of any lane of the wave has a remainder left.
+struct EuclidChain { float r0, s0, r1, s1; };
+VRC_HD void euclid_init(EuclidChain &c, bool active, int32_t ia, int32_t ib) {
+    c.r0 = (float)ib; c.s0 = 0.0f; c.r1 = active ? (float)ia : 0.0f; c.s1 = 1.0f;   // invariant: r_i == s_i * ia (mod ib)
+}
+VRC_HD void euclid_step(EuclidChain &c) {
+    const bool done = c.r1 == 0.0f;
+    float q = __builtin_floorf(c.r0 * (fast_rcp(c.r1) * 0.99999952f));   // <= floor(r0 / r1), short by < 2^-20 relative
+    q = done ? 0.0f : q;                                          // (r1 == 0: the estimate is inf; q = 0 leaves the chain as it is)
+    float n0 = __builtin_fmaf(-q, c.r1, c.r0);                    // exact, >= 0
+    const bool up = n0 >= c.r1 && !done;                          // an exact-integer ratio k floors to k - 1: one fix
+    q += up ? 1.0f : 0.0f;
+    n0 -= up ? c.r1 : 0.0f;
+    const float t0 = __builtin_fmaf(-q, c.s1, c.s0);              // exact
+    const bool swap = n0 < c.r1;                                  // a full step: the pair moves on; otherwise only r0 shrinks
+    const float nr0 = swap ? c.r1 : n0, ns0 = swap ? c.s1 : t0;
+    c.r1 = swap ? n0 : c.r1; c.s1 = swap ? t0 : c.s1;
+    c.r0 = nr0; c.s0 = ns0;
+}
+VRC_HD void euclid_finish(const EuclidChain &c, int32_t ib, int32_t &s_out, int32_t &g_out) {
+    g_out = (int32_t)c.r0;
+    int32_t s = (int32_t)c.s0;
+    s += (s < 0) ? ib : 0;
+    s_out = (s >= ib) ? 0 : s;
+}
+VRC_HD void pair_solve(bool active, int32_t ia, int32_t ib, int32_t &s_out, int32_t &g_out) {
+    EuclidChain c;
+    euclid_init(c, active, ia, ib);
+    while (VRC_WAVE_ANY(c.r1 != 0.0f)) euclid_step(c);
+    euclid_finish(c, ib, s_out, g_out);
+}
+VRC_HD uint32_t jump_entry_pack(int32_t s, int32_t g) { return (uint32_t)s | ((uint32_t)(g < 255 ? g : 255) << 24); }
+
+// Builds one row (binade kJumpFirstBinade + row, the three pairs) of the table of every lane with `active` set; the
+// other lanes idle through the loop.  A pair one of whose axes cannot have a progression in that binade gets "no entry".
+VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float dz, uint32_t *tab, int stride, uint32_t &solves) {
+    const int32_t e = kJumpFirstBinade + row;
+    const bool okx = active && jump_binade_ok(e, dx), oky = active && jump_binade_ok(e, dy), okz = active && jump_binade_ok(e, dz);
+    bool hw;
+    const int32_t ix = okx ? jump_axis_inc(e, dx, hw) : 64, iy = oky ? jump_axis_inc(e, dy, hw) : 64,
+                  iz = okz ? jump_axis_inc(e, dz, hw) : 64;
+    const bool vxy = okx && oky, vxz = okx && okz, vyz = oky && okz;
+    EuclidChain cxy, cxz, cyz;
+    euclid_init(cxy, vxy, ix, iy); euclid_init(cxz, vxz, ix, iz); euclid_init(cyz, vyz, iy, iz);
+    while (VRC_WAVE_ANY(cxy.r1 != 0.0f || cxz.r1 != 0.0f || cyz.r1 != 0.0f)) {
+        euclid_step(cxy); euclid_step(cxz); euclid_step(cyz);
+    }
+    if (active) {
+        int32_t s, g;
+        euclid_finish(cxy, iy, s, g); tab[(3 * row + 0) * stride] = vxy ? jump_entry_pack(s, g) : 0u;
+        euclid_finish(cxz, iz, s, g); tab[(3 * row + 1) * stride] = vxz ? jump_entry_pack(s, g) : 0u;
+        euclid_finish(cyz, iz, s, g); tab[(3 * row + 2) * stride] = vyz ? jump_entry_pack(s, g) : 0u;
+        solves += (vxy ? 1u : 0u) + (vxz ? 1u : 0u) + (vyz ? 1u : 0u);
+    }
+}
+// rows stretch_jump() will read for these intersection_t: one per axis pair that shares a binade inside the table
+VRC_HD uint32_t jump_rows_needed(float tx, float ty, float tz) {
+    const uint32_t rx = (f2u(tx) >> 23) - (uint32_t)kJumpFirstBinade, ry = (f2u(ty) >> 23) - (uint32_t)kJumpFirstBinade,
+                   rz = (f2u(tz) >> 23) - (uint32_t)kJumpFirstBinade;
+    uint32_t need = 0;
+    need |= (rx == ry && rx < (uint32_t)kJumpBinades) ? (1u << rx) : 0u;
+    need |= (rx == rz && rx < (uint32_t)kJumpBinades) ? (1u << rx) : 0u;
+    need |= (ry == rz && ry < (uint32_t)kJumpBinades) ? (1u << ry) : 0u;
+    return need;
+}
+// Rows are built on demand, wave-wide: `want` lanes are about to jump, `live` lanes have a ray that keeps its direction.
+// While a wanting lane lacks a row it needs, that row is built for EVERY live lane that lacks it (the rays of a tile reach
+// a binade within a few rounds of each other, and the Euclid loop costs the same for one lane as for 64).  `rows`: this
+// lane's bit mask of built rows (cleared when the ray changes direction).
+VRC_HD void jump_rows_build(bool want, bool live, uint32_t &rows, float tx, float ty, float tz, float dx, float dy, float dz,
+                            uint32_t *tab, int stride, uint32_t &solves) {
+    uint32_t need = want ? (jump_rows_needed(tx, ty, tz) & ~rows) : 0u;
+    unsigned long long m;
+    while ((m = VRC_BALLOT(need != 0u)) != 0ULL) {
+        const uint32_t first = VRC_FIRST_LANE_VALUE(need, m);
+        const int row = __builtin_ctz(first);
+        const bool build = live && !((rows >> row) & 1u);
+        jump_table_build_row(build, row, dx, dy, dz, tab, stride, solves);
+        rows |= build ? (1u << row) : 0u;
+        need &= ~rows;
+    }
+}
+VRC_HD uint32_t jump_table_entry(const uint32_t *tab, int stride, int pair, int32_t e) {
+    const uint32_t row = (uint32_t)(e - kJumpFirstBinade);
+    return row < (uint32_t)kJumpBinades ? tab[(3 * (int)row + pair) * stride] : 0u;
+}
+
+// One regular axis pair in a common binade: the consumed events are Ma + i*ia (0 <= i < ma) and Mb + j*ib (0 <= j < mb),
+// equal where i*ia - j*ib == c := Mb - Ma.  With the table's s*ia == g (mod ib): w = (c*s) mod ib equals g * i0 whenever g
+// divides c, i0 the smallest solution index -- so no solution lies below ma unless w < g * ma.
+// pair_probe() is the hot half (one modular product, straight-line so that the three pairs of a jump overlap);
+// pair_count() the warm half, entered only when a solution index may lie inside the stretch.
+struct PairProbe { int32_t w, s, g; bool may; };
+VRC_HD PairProbe pair_probe(bool active, uint32_t entry, int32_t Ma, int32_t ma, int32_t Mb, int32_t ib) {
+    PairProbe p;
+    p.s = active ? (int32_t)(entry & 0xffffffu) : 0;
+    p.g = active ? (int32_t)(entry >> 24) : 1;
+    const int32_t m = active ? ib : 64;
+    // (c * s) mod m in [0, m): the 48-bit product is exact in fp64, its quotient estimate within 2^-20 of the true one
+    const double dm = (double)m, prod = (double)(Mb - Ma) * (double)p.s;
+    const double q = __builtin_floor(prod * recip_d(m));
+    int32_t r = (int32_t)__builtin_fma(-q, dm, prod);             // exact, in (-m, 2m)
+    r += (r < 0) ? m : 0;
+    r -= (r >= m) ? m : 0;
+    p.w = r;
+    p.may = active && (uint64_t)(uint32_t)r < (uint64_t)(uint32_t)ma * (uint64_t)(uint32_t)p.g;
     return p;
 }
-
-// number of j in [0, cap] with value_j <= X, value_j = (M + j*inc) * 2^(e-23)
-VRC_HD int32_t count_le(const AxisProg &p, int32_t cap, float X, bool &ok) {
-    const uint32_t xb = f2u(X);
-    const int32_t ex = (int32_t)(xb >> 23);                       // X > 0 here
-    const int32_t Mx = (int32_t)((xb & 0x7fffffu) | 0x800000u);
-    int32_t rem;
-    const int32_t diff = Mx - p.M;
-    const int32_t j = idivmod(diff > 0 ? diff : 0, p.inc, rem, ok);
-    int32_t n = (j < cap ? j : cap) + 1;
-    n = (diff < 0) ? 0 : n;
-    n = (ex > p.e) ? cap + 1 : n;
-    n = (ex < p.e) ? 0 : n;
-    return n;
+// number of equal values; first_i / step_i / the count describe them as i = first_i + k * step_i
+struct PairTies { int32_t count, first_i, step_i; };
+VRC_HD PairTies pair_count(const PairProbe &p, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
+    PairTies out;
+    out.count = 0; out.first_i = 0; out.step_i = 1;
+    if (p.may) {
+        const int32_t c = Mb - Ma, g = p.g;
+        const double rg = recip_d(g);
+        int32_t rem, r2;
+        const int32_t cq = floordiv(c, g, rg, rem);               // g must divide c
+        if (rem == 0) {
+            const int32_t i0 = floordiv(p.w, g, rg, r2), iar = floordiv(ia, g, rg, r2), ibr = floordiv(ib, g, rg, r2);
+            // i = i0 + k*ibr pairs with j = j0 + k*iar, j0 = (i0*iar - cq) / ibr (exact; i0 < ma keeps i0*iar below 2^24)
+            const double rbr = recip_d(ibr), rar = recip_d(iar);
+            const int32_t j0 = floordiv(i0 * iar - cq, ibr, rbr, r2);
+            const int32_t k_lo = (j0 < 0) ? -floordiv(j0, iar, rar, r2) : 0;        // ceil(-j0 / iar)
+            const int32_t k_a = floordiv(ma - 1 - i0, ibr, rbr, r2);                 // >= 0
+            const int32_t k_b = floordiv(mb - 1 - j0, iar, rar, r2);                 // < 0 when j0 > mb - 1
+            const int32_t k_hi = k_a < k_b ? k_a : k_b;
+            if (k_hi >= k_lo) { out.count = k_hi - k_lo + 1; out.first_i = i0 + k_lo * ibr; out.step_i = ibr; }
+        }
+    }
+    return out;
+}
+// a table dword that cannot be used as it is: no entry (below t = 128, beyond the table) or a gcd of 255 or more
+VRC_HD bool jump_entry_unusable(uint32_t entry) { return (uint32_t)((entry >> 24) - 1u) >= 254u; }
+VRC_HD PairTies pair_ties(bool active, uint32_t entry, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
+    const bool solve = active && jump_entry_unusable(entry);
+    int32_t g_solved = 1;
+    if (VRC_WAVE_ANY(solve)) {                                    // rare: a gcd >= 255, or a caller that keeps no table
+        int32_t s2;
+        pair_solve(solve, solve ? ia : 64, solve ? ib : 64, s2, g_solved);
+        if (solve) entry = (uint32_t)s2 | (1u << 24);             // (the solved g may not fit the dword: patched in below)
+    }
+    PairProbe q = pair_probe(active, entry, Ma, ma, Mb, ib);
+    if (solve) { q.g = g_solved; q.may = (uint64_t)(uint32_t)q.w < (uint64_t)(uint32_t)ma * (uint64_t)(uint32_t)q.g; }
+    PairTies out;
+    out.count = 0; out.first_i = 0; out.step_i = 1;
+    if (VRC_WAVE_ANY(q.may)) out = pair_count(q, Ma, ia, ma, Mb, ib, mb);   // warm: a solution index may lie inside the stretch
+    return out;
 }
 
-// (g, inverse of a/g modulo b/g) by the extended Euclidean algorithm; 1 <= a, b < 2^24.
-// Runs once per axis pair and binade: kept out of line so the hot jump path stays small.
-VRC_HD_NOINLINE void gcd_inverse(int32_t a, int32_t b, int32_t &g, int32_t &inv) {
-    int32_t r0 = b, r1 = imod_loop(a, b), s0 = 0, s1 = 1;         // invariant: r_i == s_i * a (mod b)
-    while (r1 != 0) {
-        int32_t r2;
-        const int32_t q = idivmod_loop(r0, r1, r2);
-        const int32_t s2 = s0 - q * s1;
-        r0 = r1; r1 = r2; s0 = s1; s1 = s2;
-    }
-    g = r0;                                                       // gcd(a, b); s0 * a == g (mod b)
-    const int32_t bg = (g == 1) ? b : idiv_loop(b, g);
-    inv = imod_loop(s0, bg);                                      // (a/g) * inv == 1 (mod b/g)
+struct JumpAxis {
+    int32_t tb;        // bit pattern of t
+    int32_t inc;       // increment of the bit pattern per step
+    int32_t c;         // last usable event index (0 for a frozen axis)
+    int32_t e;         // biased exponent field (>= 256 for negative t)
+    int32_t m;         // events consumed
+    float E;           // value of event c
+    float last;        // value of the last consumed event
+    bool reg;          // the progression is valid (not frozen)
+    bool hitX;         // m > 0 and the last consumed value is X
+};
+
+VRC_HD JumpAxis jump_axis(float t, float d, int32_t n) {
+    JumpAxis a;
+    a.tb = (int32_t)f2u(t);
+    a.e = (int32_t)((uint32_t)a.tb >> 23);
+    bool reg = jump_binade_ok(a.e, d), halfway;
+    const int32_t ec = reg ? a.e : 64;
+    a.inc = jump_axis_inc(ec, reg ? d : 1.0f, halfway);
+    reg = reg && !(halfway && (a.tb & 1));                        // half-way case: needs an even mantissa (one real step settles it)
+    // steps that stay inside the binade: floor((2^24 - 1 - M) / inc), exact (a short estimate would cost a whole extra jump)
+    const int32_t room = floordiv_small(0x7fffff - (a.tb & 0x7fffff), reg ? a.inc : 64);
+    a.reg = reg;
+    a.c = reg ? (n - 1 < room ? n - 1 : room) : 0;
+    a.E = reg ? u2f((uint32_t)(a.tb + mul24(a.c, a.inc))) : t;
+    a.m = 0; a.last = t; a.hitX = false;
+    return a;
 }
 
-// General (cold) tie count: pairs (i, j), 0 <= i < la, 0 <= j < lb, with Ma + i*ia == Mb + j*ib.
-// first_i / step_i describe the solutions in i (first_i = -1 when there is none).
-VRC_HD_NOINLINE int32_t count_ties_general(int32_t Ma, int32_t ia, int32_t la, int32_t Mb, int32_t ib, int32_t lb,
-                                           int32_t *first_i, int32_t *step_i) {
-    *first_i = -1; *step_i = 1;
-    if (la <= 0 || lb <= 0) return 0;
-    int32_t g, inv;
-    gcd_inverse(ia, ib, g, inv);
-    int32_t c = Mb - Ma;                                          // need i*ia - j*ib == c
-    int32_t ibg = ib, iag = ia;
-    if (g != 1) {
-        int32_t rem;
-        const int32_t cq = idivmod_loop(c < 0 ? -c : c, g, rem);
-        if (rem != 0) return 0;
-        c = c < 0 ? -cq : cq;
-        ibg = idiv_loop(ib, g);
-        iag = idiv_loop(ia, g);
-    }
-    bool ok = true;
-    int32_t i0 = mulmod(imod_loop(c, ibg), inv, ibg, ok);
-    if (!ok) {                                                    // cannot happen for m < 2^24; keep exactness anyway
-        const uint64_t pr = (uint64_t)(uint32_t)imod_loop(c, ibg) * (uint64_t)(uint32_t)inv;
-        i0 = (int32_t)(pr % (uint32_t)ibg);
-    }
-    int32_t lo = 0;
-    if (c > 0) lo = idiv_loop(c + iag - 1, iag);                  // i*iag >= c
-    const int32_t first = lo + imod_loop(i0 - lo, ibg);           // smallest i >= lo with i == i0 (mod ibg)
-    if (first >= la) return 0;
-    const int32_t top = c + (lb - 1) * ibg;                       // i*iag <= c + (lb-1)*ibg
-    if (top < 0) return 0;
-    int32_t hi = idiv_loop(top, iag);
-    if (hi > la - 1) hi = la - 1;
-    if (first > hi) return 0;
-    *first_i = first; *step_i = ibg;
-    return idiv_loop(hi - first, ibg) + 1;
+// events of the axis with value <= X, where X <= a.E
+VRC_HD void jump_count(JumpAxis &a, float t, float X) {
+    const int32_t diff = (int32_t)f2u(X) - a.tb;                  // meaningful for t <= X < E: 0 <= diff < c*inc < 2^24
+    const bool mid = a.reg && X >= t && X < a.E;
+    const int32_t k = floordiv_small(mid ? diff : 0, mid ? a.inc : 64);
+    int32_t m = (X == a.E) ? a.c + 1 : k + 1;
+    m = (X >= t) ? m : 0;
+    a.m = m;
+    a.last = (a.reg && m > 0) ? u2f((uint32_t)(a.tb + mul24(m - 1, a.inc))) : t;
+    a.hitX = m > 0 && a.last == X;
 }
 
-// Cold path of try_jump: exact number of pair ties minus triple ties over the consumed events.
-VRC_HD_NOINLINE int32_t ties_minus_triples(int32_t ex, int32_t Mx, int32_t ix, int32_t mx, int32_t ey, int32_t My, int32_t iy,
-                                           int32_t my, int32_t ez, int32_t Mz, int32_t iz, int32_t mz) {
-    int32_t ties = 0, triple = 0, first, step;
-    if (ex == ey) {
-        const int32_t t_xy = count_ties_general(Mx, ix, mx, My, iy, my, &first, &step);
-        ties += t_xy;
-        if (t_xy > 0 && ez == ex && mz > 0) {                     // values common to all three axes
-            for (int32_t k = 0, i = first; k < t_xy; k++, i += step) {
-                const int32_t v = Mx + i * ix - Mz;
+// upper bound one axis puts on the end of a stretch, for the estimate the kernel makes before it decides to jump: the
+// next binade end of t, or t itself while the axis has not had its first crossing (t below delta_t: frozen)
+VRC_HD float jump_axis_limit(float t, float d) {
+    return t < d ? t : u2f((f2u(t) & 0x7f800000u) + 0x00800000u);
+}
+
+struct JumpOut {
+    int32_t iterations;    // loop iterations consumed (always >= 1)
+    bool left_node;        // the last consumed iteration zeroed a countdown (node exit / lookup pending)
+    bool capped;           // the step cap was reached before that iteration: the ray's loop has ended
+    float fx, fy, fz;      // face mask of the last consumed iteration as 0.0 / 1.0
+};
+
+// One exact multi-iteration jump.  t*, n* (countdowns >= 1) are updated in place.  `left` = iterations the loop may
+// still run (max_distance - distance_traveled, >= 1).  `tab`, `stride`: the ray's table (jump_table_build).
+VRC_HD JumpOut stretch_jump(float &tx, float &ty, float &tz, float dx, float dy, float dz, int32_t &nx, int32_t &ny,
+                            int32_t &nz, int32_t left, const uint32_t *tab, int stride) {
+    // the table dwords first: their addresses need the exponents only, and the loads have the whole decode to arrive
+    const int32_t ex0 = (int32_t)(f2u(tx) >> 23), ey0 = (int32_t)(f2u(ty) >> 23), ez0 = (int32_t)(f2u(tz) >> 23);
+    const uint32_t txy = (ex0 == ey0) ? jump_table_entry(tab, stride, 0, ex0) : 0u;
+    const uint32_t txz = (ex0 == ez0) ? jump_table_entry(tab, stride, 1, ex0) : 0u;
+    const uint32_t tyz = (ey0 == ez0) ? jump_table_entry(tab, stride, 2, ey0) : 0u;
+    JumpAxis ax = jump_axis(tx, dx, nx), ay = jump_axis(ty, dy, ny), az = jump_axis(tz, dz, nz);
+    float X = ax.E < ay.E ? ax.E : ay.E;
+    X = X < az.E ? X : az.E;
+    jump_count(ax, tx, X); jump_count(ay, ty, X); jump_count(az, tz, X);
+
+    // iterations = distinct values among the consumed events = sum - pair ties + triple ties.  Two regular axes of one
+    // binade are two integer progressions (congruence); any other pair can only meet in the value X itself.
+    const bool gxy = ax.reg && ay.reg && ax.e == ay.e, gxz = ax.reg && az.reg && ax.e == az.e, gyz = ay.reg && az.reg && ay.e == az.e;
+    const bool nxy = gxy && ax.m > 0 && ay.m > 0, nxz = gxz && ax.m > 0 && az.m > 0, nyz = gyz && ay.m > 0 && az.m > 0;
+    int32_t ties = 0, triple = 0;
+    const int32_t Mx = ax.tb & 0x7fffff, My = ay.tb & 0x7fffff, Mz = az.tb & 0x7fffff;   // (the hidden bit cancels in differences)
+    PairTies pxy;
+    pxy.count = 0; pxy.first_i = 0; pxy.step_i = 1;
+#ifndef VRC_JUMP_NO_TIES   // (timing experiment only: wrong iteration counts)
+    // one pair after the other: side by side the three modular products need more registers than the step loop leaves
+    // (measured: 116 instead of 68 bytes of scratch per lane and 0.25 ms)
+    if (VRC_WAVE_ANY(nxy)) {
+        pxy = pair_ties(nxy, txy, Mx, ax.inc, ax.m, My, ay.inc, ay.m);
+        ties += pxy.count;
+    }
+    if (VRC_WAVE_ANY(nxz)) ties += pair_ties(nxz, txz, Mx, ax.inc, ax.m, Mz, az.inc, az.m).count;
+    if (VRC_WAVE_ANY(nyz)) ties += pair_ties(nyz, tyz, My, ay.inc, ay.m, Mz, az.inc, az.m).count;
+#endif
+    // pairs outside the congruence: both last values equal X
+    ties += (!gxy && ax.hitX && ay.hitX) ? 1 : 0;
+    ties += (!gxz && ax.hitX && az.hitX) ? 1 : 0;
+    ties += (!gyz && ay.hitX && az.hitX) ? 1 : 0;
+    // values common to all three axes
+    const bool g3 = gxy && gxz;
+    triple = (!g3 && ax.hitX && ay.hitX && az.hitX) ? 1 : 0;
+    const bool cold3 = g3 && pxy.count > 0 && az.m > 0;
+    if (VRC_WAVE_ANY(cold3)) {
+        if (cold3) {
+            const double rz = recip_d(az.inc);
+            for (int32_t k = 0, i = pxy.first_i; k < pxy.count; k++, i += pxy.step_i) {
+                const int32_t v = Mx + i * ax.inc - Mz;
                 if (v >= 0) {
                     int32_t rem;
-                    const int32_t qz = idivmod_loop(v, iz, rem);
-                    if (rem == 0 && qz < mz) triple++;
+                    const int32_t qz = floordiv(v, az.inc, rz, rem);
+                    if (rem == 0 && qz < az.m) triple++;
                 }
             }
         }
     }
-    if (ex == ez) ties += count_ties_general(Mx, ix, mx, Mz, iz, mz, &first, &step);
-    if (ey == ez) ties += count_ties_general(My, iy, my, Mz, iz, mz, &first, &step);
-    return ties - triple;
-}
 
-// Per axis pair and binade `key`: inverse of inc_a modulo inc_b and of inc_b modulo inc_a, valid when the two
-// increments are coprime (flag); the increments depend on (delta_t, binade) only, so the cache holds
-// until the ray changes direction (jump_cache_reset).
-struct PairCache { int32_t key, inv_ab, inv_ba; };               // key = binade | coprime << 16, -1 = empty
-struct JumpCache { PairCache xy, xz, yz; };
-VRC_HD void jump_cache_reset(JumpCache &c) { c.xy.key = c.xz.key = c.yz.key = -1; }
-
-VRC_HD_NOINLINE void pair_fill(PairCache &pc, int32_t e, int32_t ia, int32_t ib) {
-    int32_t g, inv;
-    gcd_inverse(ia, ib, g, inv);
-    pc.inv_ab = inv;
-    int32_t g2 = 1, inv2 = 0;
-    if (g == 1) gcd_inverse(ib, ia, g2, inv2);
-    pc.inv_ba = inv2;
-    pc.key = e | ((g == 1) ? (1 << 16) : 0);
-}
-
-// Hot-path question for one axis pair in a common binade: can two consumed events be equal at all?
-// Returns false when certainly not (the overwhelmingly common case), true when the cold path must count.
-VRC_HD bool pair_may_tie(PairCache &pc, int32_t e, int32_t Ma, int32_t ia, int32_t la, int32_t Mb, int32_t ib, int32_t lb,
-                         bool &ok) {
-    if ((pc.key & 0xffff) != e || pc.key < 0) pair_fill(pc, e, ia, ib);
-    if (!(pc.key >> 16)) return true;                             // increments share a factor: let the cold path decide
-    // orient so that c <= 0: the progression that starts higher is indexed by i, i*inc_i - j*inc_j == c
-    const int32_t c = Mb - Ma;
-    const bool sw = c > 0;
-    const int32_t cc = sw ? -c : c;                               // <= 0
-    const int32_t ij = sw ? ia : ib, li = sw ? lb : la;
-    const int32_t inv = sw ? pc.inv_ba : pc.inv_ab;               // inverse of inc_i modulo inc_j
-    int32_t cm;
-    idivmod(-cc, ij, cm, ok);                                     // (-cc) mod ij
-    cm = cm ? ij - cm : 0;                                        // cc mod ij
-    const int32_t i0 = mulmod(cm, inv, ij, ok);                   // smallest i >= 0 with i*inc_i == cc (mod inc_j)
-    return i0 < li;                                               // a solution index inside the stretch: count exactly
-}
-
-struct JumpResult {
-    int32_t iterations;    // loop iterations consumed (0 = no jump taken)
-    bool left_node;        // the last consumed iteration zeroed a countdown (node exit / lookup pending)
-    bool capped;           // the step cap was reached before that iteration: the ray's loop has ended
-    int32_t fx, fy, fz;    // face mask of the last consumed iteration (valid when left_node)
-};
-
-// One exact multi-iteration jump.  t*, n* (countdowns >= 1) are updated in place.  `left` = iterations the
-// loop may still run (max_distance - distance_traveled, >= 1).
-VRC_HD JumpResult try_jump(float &tx, float &ty, float &tz, float dx, float dy, float dz,
-                           int32_t &nx, int32_t &ny, int32_t &nz, int32_t left, JumpCache &cache) {
-    JumpResult res;
-    res.iterations = 0; res.left_node = false; res.capped = false; res.fx = res.fy = res.fz = 0;
-    const AxisProg px = make_prog(tx, dx), py = make_prog(ty, dy), pz = make_prog(tz, dz);
-    if (!(px.ok && py.ok && pz.ok)) return res;
-    bool ok = true;
-
-    // last usable event index per axis: the node face (n-1) or (a lower bound of) the end of the binade
-    const int32_t cx = (nx - 1 < px.room) ? nx - 1 : px.room;
-    const int32_t cy = (ny - 1 < py.room) ? ny - 1 : py.room;
-    const int32_t cz = (nz - 1 < pz.room) ? nz - 1 : pz.room;
-    const float bxv = mk_float(px.e, px.M + cx * px.inc);
-    const float byv = mk_float(py.e, py.M + cy * py.inc);
-    const float bzv = mk_float(pz.e, pz.M + cz * pz.inc);
-    float X = bxv < byv ? bxv : byv;
-    X = X < bzv ? X : bzv;
-
-    // events consumed per axis: all values <= X
-    const int32_t mx = count_le(px, cx, X, ok), my = count_le(py, cy, X, ok), mz = count_le(pz, cz, X, ok);
-
-    // iterations = distinct values among the consumed events = sum - pair ties + triple ties
-    bool may = false;
-    if (px.e == py.e && mx > 0 && my > 0) may = may | pair_may_tie(cache.xy, px.e, px.M, px.inc, mx, py.M, py.inc, my, ok);
-    if (px.e == pz.e && mx > 0 && mz > 0) may = may | pair_may_tie(cache.xz, px.e, px.M, px.inc, mx, pz.M, pz.inc, mz, ok);
-    if (py.e == pz.e && my > 0 && mz > 0) may = may | pair_may_tie(cache.yz, py.e, py.M, py.inc, my, pz.M, pz.inc, mz, ok);
-    if (!ok) return res;                                          // an estimate failed its own check: no jump
-    int32_t iters = mx + my + mz;
-    if (may) iters -= ties_minus_triples(px.e, px.M, px.inc, mx, py.e, py.M, py.inc, my, pz.e, pz.M, pz.inc, mz);
-
-    if (iters > left) {                                           // :357 the cap ends the loop inside this stretch
+    JumpOut res;
+    res.iterations = ax.m + ay.m + az.m - ties + triple;
+    res.capped = false; res.left_node = false;
+    res.fx = ax.hitX ? 1.0f : 0.0f; res.fy = ay.hitX ? 1.0f : 0.0f; res.fz = az.hitX ? 1.0f : 0.0f;
+    if (res.iterations > left) {                                  // :357 the cap ends the loop inside this stretch
         res.iterations = left;
         res.capped = true;
         return res;
     }
-
-    // face mask of the last iteration: axes whose last consumed value is X
-    const bool lx = mx > 0 && mk_float(px.e, px.M + (mx - 1) * px.inc) == X;
-    const bool ly = my > 0 && mk_float(py.e, py.M + (my - 1) * py.inc) == X;
-    const bool lz = mz > 0 && mk_float(pz.e, pz.M + (mz - 1) * pz.inc) == X;
-
-    // new intersection_t: inside the binade by the closed form, across its end by one real float add
-    const int32_t Nx = px.M + mx * px.inc, Ny = py.M + my * py.inc, Nz = pz.M + mz * pz.inc;
-    if (mx > 0) tx = (Nx <= 0xffffff) ? mk_float(px.e, Nx) : mk_float(px.e, Nx - px.inc) + dx;
-    if (my > 0) ty = (Ny <= 0xffffff) ? mk_float(py.e, Ny) : mk_float(py.e, Ny - py.inc) + dy;
-    if (mz > 0) tz = (Nz <= 0xffffff) ? mk_float(pz.e, Nz) : mk_float(pz.e, Nz - pz.inc) + dz;
-    nx -= mx; ny -= my; nz -= mz;
-
-    res.iterations = iters;
+    // the last step of each axis is one real float add (it may leave the binade)
+    if (ax.m > 0) tx = ax.last + dx;
+    if (ay.m > 0) ty = ay.last + dy;
+    if (az.m > 0) tz = az.last + dz;
+    nx -= ax.m; ny -= ay.m; nz -= az.m;
     res.left_node = (nx == 0) || (ny == 0) || (nz == 0);
-    res.fx = lx; res.fy = ly; res.fz = lz;
     return res;
 }
 

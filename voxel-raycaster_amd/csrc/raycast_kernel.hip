@@ -42,6 +42,8 @@
 
 namespace vrc {
 
+static_assert(kJumpTableDwords == kJumpTableDwordsPerLane, "vrc_api.cpp sizes the Euclid tables with kJumpTableDwordsPerLane");
+
 // Packed stack entry of one descriptor level:
 //   bits 0-7 valid mask, 8-15 leaf mask, 16-63 absolute index of the first kept child
 __device__ __forceinline__ uint64_t make_entry(const uint64_t *__restrict__ descriptors, uint64_t index,
@@ -114,14 +116,38 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
 #endif
 enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3, kRelight = 4 };
 
-// kJump: also use the closed-form multi-iteration jumps of exact_jump.hpp (opt-in, setting jump_min_run)
+#ifdef VRC_SCHED_STATS
+// profiling build only: lane steps by run length (iterations between two node events), tools/run_hist.py
+//   [0][b] node events whose run had 2^b <= L < 2^(b+1) iterations   [1][b] the iterations of those runs
+//   [2][b] the same iterations by the bucket of the ESTIMATE made when the node was entered (run_estimate)
+__device__ unsigned long long g_run_hist[3][32];
+// [0] jump-block passes (waves)  [1] lane jumps  [2] iterations they covered  [3] jumps that left the node  [4] jumps that
+// ended at the step cap  [5] pair solves (extended Euclid)  [6] lanes that wanted a jump  [7] rounds
+__device__ unsigned long long g_jump_stats[8];
+#endif
+#ifdef VRC_TIME_STATS
+// profiling build only: shader-clock ticks (s_memtime) a wave spends per phase of a round, summed over waves
+//   [0] jump estimate + vote  [1] wave-wide Euclid fill  [2] jump block  [3] safe run  [4] single step + exact loop
+//   [5] node events  [6] relight + hit block  [7] set-up and epilogue  [8] whole kernel
+__device__ unsigned long long g_time_stats[16];
+#define VRC_TICK(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((tid & 63) == 0) t_acc[slot] += now_ - t_last; t_last = now_; } while (0)
+#else
+#define VRC_TICK(slot) do { } while (0)
+#endif
+
+// kJump: lanes whose node promises a long run take it in one closed-form jump of exact_jump.hpp (setting jump_min_run)
 // kMulti: multi-light extension (setting light_count > 1): a finished shadow ray parks the lane in kRelight and
 //         the shade phase restarts it from the first strike toward the next light
 // kTuned: the scheduling knobs are at their defaults (vrc_api.cpp), so they are compile-time constants here instead
 //         of kernarg fields held in SGPRs for the whole kernel -- the kernel sits at the SGPR and VGPR limits, and a
 //         single extra live scalar costs several per cent in spills
+// (the jump block's temporaries on top of the step-loop state: the instances with it run one block per CU fewer -- 96
+// instead of 80 registers; measured 2.81 -> 2.61 ms on the headline frame, without it the other way round)
+#ifndef VRC_MIN_BLOCKS_JUMP
+#define VRC_MIN_BLOCKS_JUMP (VRC_MIN_BLOCKS - 1)
+#endif
 template <bool kJump, bool kMulti, bool kTuned>
-__global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
+__global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
     __shared__ unsigned long long block_ctr[kCtrCount];
     const int tid = threadIdx.x;
@@ -228,6 +254,12 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         nx = ny = nz = 1.0f;
     };
 
+    // exact_jump.hpp: this lane's table of Euclid runs (one per binade and axis pair), interleaved over the wave's lanes,
+    // and the bit mask of the rows built for the ray's current direction
+    uint32_t *jtab = nullptr;
+    uint32_t jrows = 0;
+    if (kJump) jtab = p.jump_cache + ((size_t)blockIdx.x * kTilesPerBlock + (tid >> 6)) * (size_t)(kJumpTableDwords * 64) + (tid & 63);
+
     if (in_image) {
         if (!ray_setup(r, p, pix)) {
             c_unwritten = 1;
@@ -249,58 +281,108 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
     const bool use_safe = kTuned ? true : p.safe_run != 0;
     const bool use_single = kTuned ? true : p.single_step != 0;
     const int shade_threshold = kTuned ? kDefaultShadeThreshold : p.shade_threshold;
-    const float jump_min_run = (float)p.jump_min_run;
+    const float jump_min_run = kTuned ? (float)kDefaultJumpMinRun : (float)p.jump_min_run;   // estimated iterations that make a jump worth its block
     const int safe_cap = kTuned ? kDefaultSafeSteps : p.safe_steps;   // iterations per safe run (phase 2a)
     const int burst_cap = kTuned ? kDefaultBurstSteps : p.burst_steps;   // ordinary steps per round and lane (compare/select loop)
-    const int exact_cap = (!kJump && use_arith && use_safe) ? (kTuned ? kDefaultExactSteps : p.exact_steps) : burst_cap;
+    const int exact_cap = (use_arith && use_safe) ? (kTuned ? kDefaultExactSteps : p.exact_steps) : burst_cap;
     const float safe_limit = safe_t_limit(safe_cap);
-    JumpCache jcache;
-    jump_cache_reset(jcache);
 #ifdef VRC_SCHED_STATS
     // profiling build only (libvrc_stats.so): per-wave scheduler statistics; each event is counted by the
     // first active lane, so the sum over lanes is the wave-level count
     unsigned w_iters = 0, w_bursts = 0, w_ev_passes = 0, w_ev_lanes = 0, w_sh_passes = 0, w_sh_lanes = 0, w_jumps = 0;
     const int lane_id = tid & 63;
     unsigned l_try = 0, l_ok = 0, l_cov = 0;            // lane-level: jump attempts, successes, iterations covered
+    int run_start = 0, run_est_bucket = 0;              // distance_traveled when the node was entered, bucket of its estimate
+    auto note_entry = [&]() {
+        run_start = r.distance_traveled;
+        const float T = fminf(fminf(fmaf(nx - 1.0f, r.dtx, r.itx), fmaf(ny - 1.0f, r.dty, r.ity)), fmaf(nz - 1.0f, r.dtz, r.itz));
+        const float est = fmaxf(0.0f, (T - r.itx) * fabsf(r.rdx) + 1.0f) + fmaxf(0.0f, (T - r.ity) * fabsf(r.rdy) + 1.0f) +
+                          fmaxf(0.0f, (T - r.itz) * fabsf(r.rdz) + 1.0f);
+        run_est_bucket = est >= 1.0f ? 31 - __clz((int)fminf(est, 1e9f)) : 0;
+    };
+    if (mode == kStep) note_entry();
 #define VRC_STAT(var, inc) do { if (lane_id == __ffsll((long long)__ballot(true)) - 1) var += (inc); } while (0)
 #else
 #define VRC_STAT(var, inc) do { } while (0)
 #endif
     int rounds_left = p.watchdog_rounds;
+#ifdef VRC_TIME_STATS
+    unsigned long long t_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t_last;
+#endif
     for (;;) {
         // One round = every live lane advances to its next node event: a closed-form jump (long empty
         // stretch) or a burst of ordinary steps (short stretch / not yet in the closed-form regime), then all
         // parked lanes are serviced together, so each phase runs with as many lanes as possible.
 
-        // ---- phase 1: exact multi-iteration jumps (exact_jump.hpp)
-        if (kJump && mode == kStep && fminf(fminf(nx, ny), nz) >= jump_min_run) {
-#pragma nounroll
-            for (int attempt = 0; attempt < 2 && mode == kStep; attempt++) {
-                int inx = (int)nx, iny = (int)ny, inz = (int)nz;
-                const JumpResult jr = try_jump(r.itx, r.ity, r.itz, r.dtx, r.dty, r.dtz, inx, iny, inz,
-                                               r.max_distance - r.distance_traveled, jcache);
+        // ---- phase 1: exact closed-form jumps (exact_jump.hpp) for the lanes whose node promises a long run.  The
+        // estimate is the one a safe run would make (time of the node exit, here also cut at the next binade end of each
+        // axis and at a slow axis that has not had its first crossing: stretch_jump() stops there), turned into iterations.
+        if (kJump) {
+            bool want = false;
+            if (mode == kStep) {
+                float X = fminf(fminf(fmaf(nx - 1.0f, r.dtx, r.itx), fmaf(ny - 1.0f, r.dty, r.ity)), fmaf(nz - 1.0f, r.dtz, r.itz));
+                X = fminf(X, fminf(fminf(jump_axis_limit(r.itx, r.dtx), jump_axis_limit(r.ity, r.dty)), jump_axis_limit(r.itz, r.dtz)));
+                const float est = fmaxf(0.0f, fmaf(X - r.itx, fabsf(r.rdx), 1.0f)) + fmaxf(0.0f, fmaf(X - r.ity, fabsf(r.rdy), 1.0f)) +
+                                  fmaxf(0.0f, fmaf(X - r.itz, fabsf(r.rdz), 1.0f));
+                want = est >= jump_min_run;
+            }
+            const unsigned long long wj = __ballot(want);
+            VRC_TICK(0);
 #ifdef VRC_SCHED_STATS
-                l_try++; if (jr.iterations > 0) { l_ok++; l_cov += jr.iterations; }
+            if (lane_id == 0) atomicAdd(&g_jump_stats[7], 1ULL);
+            if (want) atomicAdd(&g_jump_stats[6], 1ULL);
 #endif
-                if (jr.iterations == 0) break;            // not in the closed-form regime: ordinary steps below
-                VRC_STAT(w_jumps, 1);
-                if (jr.capped) {                          // :357 the step cap ends the loop inside the stretch
-                    r.distance_traveled = r.max_distance;
-                    mode = ended();
-                } else {
-                    nx = (float)inx; ny = (float)iny; nz = (float)inz;
-                    if (jr.left_node) {
-                        fxf = (float)jr.fx; fyf = (float)jr.fy; fzf = (float)jr.fz;
-                        r.distance_traveled += jr.iterations - 1;     // the leaving iteration's :714 follows the lookup
-                        mode = kEvent;
-                    } else {                              // stopped at a binade boundary: try once more
-                        r.distance_traveled += jr.iterations;
-                        if (r.distance_traveled >= r.max_distance) mode = ended();
+            // (one lane is enough: holding the block back until 4 / 8 / 16 / 32 lanes want it -- the lanes that do standing
+            // still meanwhile, or stepping on -- measured 2.73 / 2.82 / 2.85 / 3.10 ms against 2.59 on the headline frame)
+            if (wj != 0ULL) {
+#ifdef VRC_SCHED_STATS
+                if (lane_id == __ffsll((long long)wj) - 1) atomicAdd(&g_jump_stats[0], 1ULL);
+#endif
+                {   // the table rows the jumps will read: built for every lane whose ray keeps its direction
+                    uint32_t solves = 0;
+                    asm volatile("; VRC_MARK jump_rows_begin");
+#ifndef VRC_JUMP_NO_FILL   // (timing experiment only, with VRC_JUMP_NO_TIES)
+                    jump_rows_build(want, mode == kStep || mode == kEvent, jrows, r.itx, r.ity, r.itz, r.dtx, r.dty, r.dtz, jtab, 64, solves);
+#endif
+                    asm volatile("; VRC_MARK jump_rows_end");
+                    VRC_TICK(1);
+#ifdef VRC_SCHED_STATS
+                    if (solves) atomicAdd(&g_jump_stats[5], (unsigned long long)solves);
+#endif
+                }
+                if (want) {
+                    asm volatile("; VRC_MARK jump_block_begin");
+                    int inx = (int)nx, iny = (int)ny, inz = (int)nz;
+                    const JumpOut jo = stretch_jump(r.itx, r.ity, r.itz, r.dtx, r.dty, r.dtz, inx, iny, inz,
+                                                    r.max_distance - r.distance_traveled, jtab, 64);
+#ifdef VRC_SCHED_STATS
+                    atomicAdd(&g_jump_stats[1], 1ULL);
+                    atomicAdd(&g_jump_stats[2], (unsigned long long)jo.iterations);
+                    if (jo.left_node) atomicAdd(&g_jump_stats[3], 1ULL);
+                    if (jo.capped) atomicAdd(&g_jump_stats[4], 1ULL);
+#endif
+                    if (jo.capped) {                          // :357 the step cap ends the loop inside the stretch
+                        r.distance_traveled = r.max_distance;
+                        mode = ended();
+                    } else {
+                        nx = (float)inx; ny = (float)iny; nz = (float)inz;
+                        if (jo.left_node) {
+                            fxf = jo.fx; fyf = jo.fy; fzf = jo.fz;
+                            r.distance_traveled += jo.iterations - 1;     // the leaving iteration's :714 follows the lookup
+                            mode = kEvent;
+                        } else {                              // stopped at a binade end / a frozen axis: the next round goes on
+                            r.distance_traveled += jo.iterations;
+                            if (r.distance_traveled >= r.max_distance) mode = ended();
+                        }
                     }
+                    asm volatile("; VRC_MARK jump_block_end");
                 }
             }
         }
 
+        VRC_TICK(2);
         // the arithmetic face_mask of the step loop needs every t to be 0 or >= 2^-100.  t only grows by
         // delta_t >= 1/2 per step, so once a lane is safe it stays safe until its ray is restarted (t_unsafe is set
         // again there); a wave with an unsafe stepping lane takes the compare/select loop for this burst.
@@ -312,7 +394,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         // steps): no exec masking, scalar loop control, kSafeUnroll iterations per loop trip (the vote and the scalar
         // branch are not free: 2 -> 4 -> 8 -> 16 -> 32 iterations per trip measured 3.30 -> 3.11 -> 3.09 -> 3.03 -> 3.14 ms).
         bool deep = false;                                // still far from the node face after the safe run
-        if (!kJump && arith_mask && use_safe && safe_cap >= kSafeUnroll) {
+        if (arith_mask && use_safe && safe_cap >= kSafeUnroll) {
             SafeGate gate;
             if (mode == kStep && r.max_distance - r.distance_traveled >= safe_cap) {
                 const float T = fminf(fminf(safe_threshold(r.itx, r.dtx, nx), safe_threshold(r.ity, r.dty, ny)),
@@ -354,12 +436,13 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
             }
         }
 
+        VRC_TICK(3);
         // ---- phase 2b: one exact step for the lanes that are not deep inside a node.  A lane that has just reached
         // its safe-run threshold is almost always exactly one iteration from the node face (the threshold is within
         // n 2^-23 relative of the crossing time), and so is a lane in a freshly entered one-voxel node: one
         // straight-line iteration with countdowns sends them to the event phase, and the exact loop below only runs
         // for what is left (lanes near their step cap, t outside the arithmetic range, rare two-step leftovers).
-        if (!kJump && arith_mask && use_single && mode == kStep && !deep) {
+        if (arith_mask && use_single && mode == kStep && !deep) {
             const float m = fminf(fminf(r.itx, r.ity), r.itz);
             const float gx = alive_if_zero(r.itx - m, 1.0f);              // :558
             const float gy = alive_if_zero(r.ity - m, 1.0f);
@@ -383,8 +466,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         // (skipped when every stepping lane of the wave is still deep inside its node: the next safe run takes them on)
         if (mode == kStep && __ballot(mode == kStep && !deep) != 0ULL) {
             const int true_limit = r.max_distance - r.distance_traveled;     // >= 1 iterations left (:357)
-            const int cap = (kJump && fminf(fminf(nx, ny), nz) >= jump_min_run) ? 2 : exact_cap;
-            const int it_limit = true_limit < cap ? true_limit : cap;
+            const int it_limit = true_limit < exact_cap ? true_limit : exact_cap;
             float left = (float)it_limit;                  // per-lane countdown (exact: < 2^24)
             bool go;
             if (arith_mask) {
@@ -446,6 +528,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
                 if (it == true_limit) mode = ended();     // :357
             }
         }
+        VRC_TICK(4);
         const unsigned long long ev = __ballot(mode == kEvent);
         const unsigned long long st = __ballot(mode == kStep);
         unsigned long long sh = __ballot(mode == kShade || (kMulti && mode == kRelight));
@@ -457,6 +540,15 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
         if (ev != 0ULL) {
             VRC_STAT(w_ev_passes, 1); VRC_STAT(w_ev_lanes, __popcll(ev));
             if (mode == kEvent) {
+#ifdef VRC_SCHED_STATS
+                {
+                    const int L = r.distance_traveled + 1 - run_start;
+                    const int b = L >= 1 ? 31 - __clz(L) : 0;
+                    atomicAdd(&g_run_hist[0][b], 1ULL);
+                    atomicAdd(&g_run_hist[1][b], (unsigned long long)(L > 0 ? L : 0));
+                    atomicAdd(&g_run_hist[2][run_est_bucket], (unsigned long long)(L > 0 ? L : 0));
+                }
+#endif
                 r.vx = r.sx > 0 ? bx - (int)nx : bx + (int)nx;   // voxel = base - step * countdown, step = +-1
                 r.vy = r.sy > 0 ? by - (int)ny : by + (int)ny;
                 r.vz = r.sz > 0 ? bz - (int)nz : bz + (int)nz;
@@ -471,6 +563,9 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
                         enter_node(b);
                         r.distance_traveled++;            // :714
                         mode = (r.distance_traveled < r.max_distance) ? kStep : ended();   // :357
+#ifdef VRC_SCHED_STATS
+                        note_entry();
+#endif
                     } else {
                         mat = solid_material(r.vx, r.vy, r.vz);
                         if ((mat == 5 || mat == 6) && r.shadow_ray) {   // :575, :707-710
@@ -483,6 +578,9 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
                             enter_single();
                             r.distance_traveled++;        // :714
                             mode = (r.distance_traveled < r.max_distance) ? kStep : ended();   // :357
+#ifdef VRC_SCHED_STATS
+                            note_entry();
+#endif
                         }
                     }
                 }
@@ -490,6 +588,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
             sh = __ballot(mode == kShade || (kMulti && mode == kRelight));
         }
 
+        VRC_TICK(5);
         // ---- phase 4a (multi-light): a lane whose shadow ray has ended goes back to the first strike for the next light;
         // cheap next to the hit block, so it need not wait for the whole tile (VRC_RELIGHT_THRESHOLD lanes, or nothing left
         // to step)
@@ -506,9 +605,12 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
                     steps_base += r.distance_traveled + (int)broke - (r.kdist + 1);
                     broke = 0;
                     enter_single();
-                    if (kJump) jump_cache_reset(jcache);
+                    jrows = 0;                            // delta_t changed: the table of exact_jump.hpp is stale
                     r.distance_traveled = r.kdist + 1;    // as if the strike iteration had just finished (:714)
                     mode = (r.distance_traveled < r.max_distance) ? kStep : ended();
+#ifdef VRC_SCHED_STATS
+                    note_entry();
+#endif
                 }
             }
             }
@@ -527,12 +629,16 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
                 } else {
                     enter_single();
                     t_unsafe = true;
-                    if (kJump) jump_cache_reset(jcache);  // delta_t changed with the redirect
+                    jrows = 0;                            // delta_t changed with the redirect: the table of exact_jump.hpp is stale
                     r.distance_traveled++;                // :714
                     mode = (r.distance_traveled < r.max_distance && (r.counts >> 16) < 2) ? kStep : ended();   // :357
+#ifdef VRC_SCHED_STATS
+                    note_entry();
+#endif
                 }
             }
         }
+        VRC_TICK(6);
     }
 
     if (rounds_left < 0 && (tid & 63) == 0) {
@@ -558,6 +664,15 @@ __global__ __launch_bounds__(kBlockThreads, VRC_MIN_BLOCKS) void raycast_svo_ker
     if (l_try) atomicAdd(&block_ctr[kCtrShadeLanes + 1], (unsigned long long)l_try);
     if (l_ok) atomicAdd(&block_ctr[kCtrShadeLanes + 2], (unsigned long long)l_ok);
     if (l_cov) atomicAdd(&block_ctr[kCtrMap], (unsigned long long)l_cov);
+#endif
+#ifdef VRC_TIME_STATS
+    {
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();
+        if ((tid & 63) == 0) {
+            t_acc[8] = now_ - t_begin;
+            for (int k = 0; k < 9; k++) atomicAdd(&g_time_stats[k], t_acc[k]);
+        }
+    }
 #endif
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
     publish_counters(p, block_ctr, vals);
@@ -625,6 +740,34 @@ __global__ void pack_rgba8_kernel(const float4 *__restrict__ image, uchar4 *__re
     out[i] = make_uchar4(q(v.x), q(v.y), q(v.z), q(v.w));
 }
 
+#ifdef VRC_TIME_STATS
+}  // namespace vrc
+extern "C" int vrc_stats_time(unsigned long long *out16, int clear) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(vrc::g_time_stats), sizeof(vrc::g_time_stats)) != hipSuccess) return 1;
+    if (clear) {
+        static unsigned long long zero[16];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vrc::g_time_stats), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+namespace vrc {
+#endif
+#ifdef VRC_SCHED_STATS
+}  // namespace vrc
+// profiling build only (tools/run_hist.py): read / clear the run-length histogram
+extern "C" int vrc_stats_run_hist(unsigned long long *out96, int clear) {   // out: 96 histogram + 8 jump counters
+    if (out96 && hipMemcpyFromSymbol(out96, HIP_SYMBOL(vrc::g_run_hist), sizeof(vrc::g_run_hist)) != hipSuccess) return 1;
+    if (out96 && hipMemcpyFromSymbol(out96 + 96, HIP_SYMBOL(vrc::g_jump_stats), sizeof(vrc::g_jump_stats)) != hipSuccess) return 1;
+    if (clear) {
+        static unsigned long long zero[3][32];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vrc::g_run_hist), zero, sizeof(zero)) != hipSuccess) return 1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vrc::g_jump_stats), zero, sizeof(vrc::g_jump_stats)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+namespace vrc {
+#endif
+
 hipError_t launch_fill_image(float *image, size_t n_pixels, hipStream_t stream) {
     (void)hipGetLastError();                 // an error an earlier call left behind is not this launch's
     if (!n_pixels) return hipSuccess;
@@ -656,17 +799,24 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
     if (p.svo) {
         const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
         const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t) + (size_t)p.lds_pad_bytes;
-        const bool jump = p.jump_min_run < (1 << 24), multi = p.light_count > 1;
-        const bool tuned = !jump && p.widen_nodes != 0 && p.arith_mask != 0 && p.safe_run != 0 && p.single_step != 0 &&
+        const bool jump = p.jump_min_run < kJumpOff, multi = p.light_count > 1;
+        const bool tuned = (!jump || p.jump_min_run == kDefaultJumpMinRun) &&
+                           p.widen_nodes != 0 && p.arith_mask != 0 && p.safe_run != 0 && p.single_step != 0 &&
                            p.shade_threshold == kDefaultShadeThreshold && p.safe_steps == kDefaultSafeSteps &&
                            p.exact_steps == kDefaultExactSteps && p.burst_steps == kDefaultBurstSteps;
+        if (jump && !p.jump_cache) return hipErrorInvalidValue;
 #define VRC_LAUNCH(J, M, T) hipLaunchKernelGGL((raycast_svo_kernel<J, M, T>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p)
-        if (jump && multi) VRC_LAUNCH(true, true, false);
-        else if (jump) VRC_LAUNCH(true, false, false);
-        else if (multi && tuned) VRC_LAUNCH(false, true, true);
-        else if (multi) VRC_LAUNCH(false, true, false);
-        else if (tuned) VRC_LAUNCH(false, false, true);
-        else VRC_LAUNCH(false, false, false);
+        if (jump) {
+            if (multi && tuned) VRC_LAUNCH(true, true, true);
+            else if (multi) VRC_LAUNCH(true, true, false);
+            else if (tuned) VRC_LAUNCH(true, false, true);
+            else VRC_LAUNCH(true, false, false);
+        } else {
+            if (multi && tuned) VRC_LAUNCH(false, true, true);
+            else if (multi) VRC_LAUNCH(false, true, false);
+            else if (tuned) VRC_LAUNCH(false, false, true);
+            else VRC_LAUNCH(false, false, false);
+        }
 #undef VRC_LAUNCH
     } else {
         hipLaunchKernelGGL(raycast_array_kernel, dim3(nblocks), dim3(kBlockThreads), 0, stream, p);

@@ -48,6 +48,7 @@ struct vrc_caster {
     bool owns_desc = true;                // false: a group rank on the same GPU as rank 0 shares rank 0's arrays
     uint32_t *d_attach_lookup = nullptr; uint64_t *d_attach = nullptr; uint64_t n_attach = 0;
     float *d_viewport = nullptr; float *d_image = nullptr; int32_t *d_hits = nullptr; uint8_t *d_rgba8 = nullptr;
+    uint32_t *d_jump_cache = nullptr; size_t jump_cache_bytes = 0;   // per-ray Euclid tables of the exact closed-form jumps (exact_jump.hpp)
     int32_t width = 0, height = 0;
     bool sliced = false;                  // viewport / image / hits hold only this rank's rows
     int32_t buffer_rows = 0;              // rows the three buffers hold
@@ -196,7 +197,7 @@ void reference_table_row(int32_t width, int32_t height, int32_t row, float *out)
 // table == nullptr: the reference's own table
 int install_viewport(vrc_caster *h, int32_t width, int32_t height, const float *table) {
     HIP_TRY(h, hipSetDevice(h->device));
-    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8);
+    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_jump_cache);
     h->width = width; h->height = height;
     h->buffer_rows = h->sliced ? local_row_count(h) : height;
     h->validated = false;
@@ -224,6 +225,17 @@ int install_viewport(vrc_caster *h, int32_t width, int32_t height, const float *
     // the image starts as RGBA8 (255,255,255,100)  (CLCaster.cpp:280-286)
     HIP_TRY(h, vrc::launch_fill_image(h->d_image, npix, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return VRC_OK;
+}
+
+// the per-ray Euclid tables of the exact closed-form jumps (exact_jump.hpp): kJumpTableDwordsPerLane dwords per lane of every block
+int ensure_jump_cache(vrc_caster *h, int nblocks) {
+    const size_t bytes = (size_t)nblocks * vrc::kBlockThreads * vrc::kJumpTableDwordsPerLane * sizeof(uint32_t);
+    if (h->d_jump_cache && h->jump_cache_bytes >= bytes) return VRC_OK;
+    release(h->d_jump_cache);
+    h->jump_cache_bytes = 0;
+    HIP_TRY(h, hipMalloc((void **)&h->d_jump_cache, bytes));      // every ray writes its whole table before it reads it
+    h->jump_cache_bytes = bytes;
     return VRC_OK;
 }
 
@@ -337,7 +349,7 @@ int vrc_destroy(vrc_caster *h) {
     for (auto &p : h->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     release_tree(h);
     release(h->d_map);
-    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_atlas);
+    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_jump_cache); release(h->d_atlas);
     release(h->d_partials); release(h->d_counters); release(h->d_frame);
     if (h->wd_flag) (void)hipHostFree(h->wd_flag);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -619,7 +631,7 @@ int vrc_create_viewport_table(vrc_caster *h, int32_t width, int32_t height, cons
 int vrc_release_viewport(vrc_caster *h) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_viewport) return fail(h, VRC_ERR_NOT_FOUND, "release_viewport: no viewport");
-    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8);
+    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_jump_cache);
     h->width = h->height = h->buffer_rows = 0; h->validated = false;
     FOR_PEERS(h, vrc_release_viewport(q));
     return VRC_OK;
@@ -801,7 +813,9 @@ int compute_async_one(vrc_caster *h) {
     // wave scheduling knobs of the SVO kernel; they never change results
     p.burst_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "burst_steps", vrc::kDefaultBurstSteps)));
     p.shade_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "shade_threshold", vrc::kDefaultShadeThreshold)));
-    p.jump_min_run = (int32_t)std::min<int64_t>(1 << 24, std::max<int64_t>(1, setting_or(h, "jump_min_run", 1 << 24)));
+    p.jump_min_run = (int32_t)std::min<int64_t>(vrc::kJumpOff, std::max<int64_t>(1, setting_or(h, "jump_min_run",
+                                    p.log2_dim >= vrc::kDefaultJumpMinDepth ? vrc::kDefaultJumpMinRun : vrc::kJumpOff)));
+
     p.widen_nodes = (int32_t)setting_or(h, "widen_nodes", 1);
     p.octree_bias = (int32_t)setting_or(h, "octree_bias", 1);
     p.arith_mask = (int32_t)setting_or(h, "arith_mask", 1);
@@ -839,6 +853,11 @@ int compute_async_one(vrc_caster *h) {
         h->partial_blocks = nblocks;
     }
     p.counters = h->d_partials;
+    if (svo && p.stepping_mode == 0 && p.jump_min_run < vrc::kJumpOff) {
+        const int rc = ensure_jump_cache(h, nblocks);
+        if (rc != VRC_OK) return rc;
+        p.jump_cache = h->d_jump_cache;
+    }
     h->last_blocks = nblocks;
     h->frames_enqueued++;
 
