@@ -138,7 +138,7 @@ def reduce_over_ranks(rays: int, seconds: float):
     """(SUM of rays, MAX of seconds) over all ranks; identity when not distributed."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return rays, seconds
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     r = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
@@ -211,12 +211,12 @@ def ray_cpp_baseline():
             "workload": "configs[0]: 256^3 dense grid, 640x480, Ray::Cast restated (600-step cap)", "dda_steps": steps}
 
 
-def shared_scene(depth, rank, world, tag):
+def shared_scene(depth, rank, world, tag, dist_on=False):
     """The scene is built ONCE: rank 0 builds it and saves the tree (vrc_octree_save); the other ranks stream the file
     straight into their own HBM (vrc_assign_octree_file) and never hold a host copy.  Returns (scene dict, file or None)."""
     import torch.distributed as dist
     import voxel_raycaster_amd as vrc
-    if world == 1:
+    if not dist_on:
         return build_scene(depth), None
     path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"vrc_bench_{tag}.svo")
     meta = [None]
@@ -274,14 +274,19 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # VRC_BENCH_FORCE_DIST=1 (a 1-GPU box under `torchrun --nproc-per-node 1`): take the distributed code path -- process
+    # group on the real nccl (= RCCL) backend, barriers, broadcast_object_list of the scene header, tree handed over
+    # through a file, SUM/MAX all_reduce -- with a world of one, so that it has run on hardware at least once
+    dist_on = world > 1 or os.environ.get("VRC_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # RCCL: barrier + scalar reductions only
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
         barrier(local_rank)                # rank 0's build is finished before any other rank imports the library
     import voxel_raycaster_amd  # noqa: F401  (fails loudly if the HIP library is missing)
 
-    sc, tree_file = shared_scene(args.depth, rank, world, os.environ.get("MASTER_PORT", "0"))
+    sc, tree_file = shared_scene(args.depth, rank, world, os.environ.get("MASTER_PORT", "0"), dist_on)
     if tree_file and rank == 0:                                # /dev/shm is memory: the file must not outlive a failed run
         import atexit
         atexit.register(lambda: os.path.exists(tree_file) and os.remove(tree_file))
@@ -294,10 +299,23 @@ def main():
     c = make_caster(sc, W, full_h, local_rank, table=table, row_slice=None if world == 1 else (rank, world, 8),
                     octree_file=None if rank == 0 else tree_file, hit_records=0)
     del table
-    if world > 1:
+    if dist_on:
         barrier(local_rank)
         if rank == 0 and os.path.exists(tree_file):
             os.remove(tree_file)
+
+    # what a caller sees without any pre-warming: the first `steps` frames of this fresh process (clocks still ramping),
+    # reported beside `value` as value_no_prewarm
+    assert c.compute(), c.last_error()                             # (first launch: code object load)
+    ctr0 = c.counters()
+    torch.cuda.synchronize()
+    tc = time.perf_counter()
+    for _ in range(args.steps):
+        if not c.compute():
+            raise SystemExit("compute failed: " + c.last_error())
+    torch.cuda.synchronize()
+    cold_dt = time.perf_counter() - tc
+    value_no_prewarm = (ctr0["primary_rays"] + ctr0["shadow_rays"]) * args.steps / cold_dt / 1e6      # this rank's rows
 
     # set-up, not measurement: a fresh process finds the GPU at its idle clocks, and a 3 ms kernel needs a few dozen
     # launches before DVFS settles (measured: the first timed block of a run is 2-3 % slower than the second)
@@ -311,14 +329,14 @@ def main():
     rays_per_step = ctr["primary_rays"] + ctr["shadow_rays"]
     c.timing_reset()
 
-    if world > 1:
+    if dist_on:
         barrier(local_rank)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if not c.compute():
             raise SystemExit("compute failed: " + c.last_error())
-    if world > 1:
+    if dist_on:
         barrier(local_rank)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -358,13 +376,15 @@ def main():
             "metric": "Mrays/s (primary+shadow), 1920x1080 into depth-12 SVO",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(max_dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "value_no_prewarm": round(value_no_prewarm, 3) if world == 1 else None,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: {sc['dim']}^3 (depth-{args.depth}) shell-terrain SVO seed 1, "
                                    f"{W}x{H}{'' if world == 1 else f' x{world} rows (vertical supersampling)'}, "
                                    "primary + 1-light shadow + Blinn-Phong + texture atlas, max_distance 3*dim",
                        "descriptors": int(sc["octree"].descriptor_buffer.size),
                        "rays_per_step": int(total_rays), "parallelism": f"row-slices x{world}, SVO replicated",
-                       "stepping": "exact per-voxel DDA (bit-identical to the reference array branch)",
+                       "stepping": "exact per-voxel DDA (bit-identical to the reference array branch); long empty runs in closed form "
+                                   "(exact_jump.hpp: same float sequence and iteration count), setting jump_min_run",
                        "prewarm_frames": PREWARM_FRAMES,
                        "frame": "production frame: image only, like the reference (hit_records = 0); with_hit_records is the same frame plus the parity records"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -379,8 +399,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out.update(supplementary(sc, c, W, H, local_rank, args, rays_per_step))
+        if dist_on and world == 1:
+            out["config"]["distributed_path"] = f"forced on a world of one ({dist.get_backend()}): barrier, broadcast_object_list, all_reduce executed"
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         barrier(local_rank)
         dist.destroy_process_group()
 

@@ -171,8 +171,17 @@ int vrc_set_row_slice(vrc_caster *h, int32_t rank, int32_t world, int32_t band_r
  * -- vrc_read_* gather every rank's rows into the caller's frame (each GPU copies its own tile, no collective),
  * vrc_get_counters sums the ranks.  vrc_destroy on the group handle destroys all ranks.                            */
 int vrc_create_group(const int32_t *device_ordinals, int32_t n, int32_t band_rows, vrc_caster **out);
+/* The same with flags.  VRC_GROUP_OWN_COPIES: ranks that sit on rank 0's own GPU do not share its arrays but take the
+ * path a rank on another GPU takes -- own allocation, hipMemcpyPeerAsync, attachment re-copy, release -- so that the
+ * multi-GPU code can be exercised on a machine with one GPU (vrc_create_group honours VRC_GROUP_OWN_COPIES=1 in the
+ * environment).  After a successful creation vrc_last_error() names the ranks whose GPU has no direct peer access to
+ * rank 0's (their copies are staged by the runtime); it is empty otherwise.                                          */
+#define VRC_GROUP_OWN_COPIES 1u
+int vrc_create_group_ex(const int32_t *device_ordinals, int32_t n, int32_t band_rows, uint32_t flags, vrc_caster **out);
 int vrc_group_size(const vrc_caster *h, int32_t *n);
-/* Pin / unpin a caller-owned frame buffer so the per-rank tile copies overlap (hipHostRegister). */
+/* Pin / unpin a caller-owned frame buffer (hipHostRegister): a group then copies every rank's tile straight into it.
+ * A pageable destination works too -- each rank stages its tile through a pinned buffer of its own so that the n copies
+ * still run side by side, at the price of one more host copy.                                                        */
 int vrc_pin_host_buffer(void *p, size_t bytes);
 int vrc_unpin_host_buffer(void *p);
 /* Device memory held by one rank of a group (rank 0 = the handle itself). */
@@ -180,6 +189,7 @@ typedef struct vrc_memory {
     int32_t  device, rows;            /* GPU ordinal; rows of the frame this rank's buffers hold */
     uint64_t viewport_bytes, image_bytes, hit_bytes, octree_bytes;
     int32_t  octree_shared;           /* 1: the arrays belong to rank 0 (same GPU) */
+    int32_t  peer_access;             /* -1: rank 0 or on rank 0's GPU; 1: direct peer access to rank 0's GPU; 0: staged by the runtime */
 } vrc_memory;
 int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out);
 

@@ -6,6 +6,7 @@
  */
 #include "vrc_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -476,7 +477,9 @@ typedef struct {
 } jump_state;
 
 static void jump_set_ray(jump_state *j, const float origin[3], const float rd[3]) {
-    for (int a = 0; a < 3; a++) { j->origin[a] = origin[a]; j->inv[a] = 1.0f / rd[a]; }
+    /* 1 / a denormal component is inf and 0 * inf (a ray starting exactly on a plane) NaN: clamped to the largest float,
+     * as the kernel does (raycast_jump_kernel.hip set_ray), so that every jump has a minimum and makes progress */
+    for (int a = 0; a < 3; a++) { j->origin[a] = origin[a]; j->inv[a] = fminf(fmaxf(1.0f / rd[a], -FLT_MAX), FLT_MAX); }
 }
 /* A restarted ray (:677-679 shadow, :700-702 mirror).  The reference sets intersection_t = delta_t * frac(hit_pos) *
  * voxel_step (+ delta_t where negative): the distance to the next plane is frac for rays going up an axis and 1 - frac

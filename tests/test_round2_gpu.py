@@ -536,3 +536,107 @@ def test_atlas_and_tile_shapes_other_than_the_apps(shape, make, using_octree):
                                     attachment_lookup=o.attachment_lookup, attachments=o.attachment_buffer)
     assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
     assert octr["n_tex"] > 0 and (ohits[..., 3] == (6 if make is scenes.mirror_wall else 5)).any()
+
+
+# ------------------------------------------------------------------ round 3: the distinct-GPU code paths, rehearsed on one GPU
+def test_group_with_own_copies_takes_the_cross_device_path(atlas):
+    """VRC_GROUP_OWN_COPIES: every rank sits on GPU 0 (all this box has) but takes the path of a rank on another GPU --
+    own allocation + hipMemcpyPeerAsync of the tree, attachment re-copy, release -- on the depth-12 tree with
+    attachments, 4 ranks.  Frame, hit records, RGBA8 and counters equal the single handle's; no rank shares rank 0's
+    arrays.  (A same-GPU rehearsal: no 8-GPU hardware run exists, and no scaling number is claimed.)"""
+    sc = bench_scene(12)
+    dim, w, h = sc["dim"], 1280, 720
+    tree = sc["octree"]
+    if tree.attachment_lookup is None:
+        tree.attach_materials_procedural(12, seed=1, mirror_period=64)
+    one = vrc.CLCaster()
+    assert one.init(0) and one.assign_octree(tree)
+    configure(one, dim, sc["atlas"], sc["cam_dir"], sc["cam_pos"], sc["lights"], w, h)
+    assert one.validate() and one.compute()
+    ref_img, ref_hits, ref_rgba, ref_ctr = one.read_image(), one.read_hits(), one.read_image_rgba8(), one.counters()
+    assert (ref_hits[..., 3] == 6).sum() > 100                       # the mirrors of the attachments are in the picture
+    g = vrc.CLCaster()
+    assert g.init_group([0] * 4, band_rows=8, own_copies=True) and g.group_size() == 4
+    assert g.last_error() == ""                                      # no peer-access fallback to report on one GPU
+    assert g.assign_octree(tree)                                     # tree, then attachments: fan-out + attachment re-fan-out
+    configure(g, dim, sc["atlas"], sc["cam_dir"], sc["cam_pos"], sc["lights"], w, h)
+    assert g.validate() and g.compute(), g.last_error()
+    mem = [g.memory_usage(r) for r in range(4)]
+    n_desc = tree.descriptor_buffer.size
+    per_rank = n_desc * 8 + n_desc * 4 + tree.attachment_buffer.size * 8
+    assert all(m["octree_shared"] == 0 and m["octree_bytes"] == per_rank for m in mem), mem
+    assert all(m["peer_access"] == -1 for m in mem)
+    # pageable destination: every rank stages its tile through its own pinned buffer; pinned destination: direct
+    img = g.read_image()
+    assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32))
+    pinned = np.zeros_like(ref_img)
+    vrc.pin_host_buffer(pinned)
+    try:
+        g.read_image(out=pinned)
+        assert np.array_equal(pinned.view(np.uint32), ref_img.view(np.uint32))
+    finally:
+        vrc.unpin_host_buffer(pinned)
+    assert np.array_equal(g.read_hits(), ref_hits) and np.array_equal(g.read_image_rgba8(), ref_rgba) and g.counters() == ref_ctr
+    # a rejected attachment call leaves EVERY rank as it was (the check comes before anything is released)
+    import ctypes as C
+    bad = tree.attachment_lookup.copy()
+    bad[7] = tree.attachment_buffer.size + 1
+    rc = vrc.lib.vrc_assign_octree_attachments(g._h, bad.ctypes.data_as(C.POINTER(C.c_uint32)), bad.size,
+                                               tree.attachment_buffer.ctypes.data_as(C.POINTER(C.c_uint64)), tree.attachment_buffer.size)
+    assert rc == 1 and "past the attachment buffer" in g.last_error()
+    assert [g.memory_usage(r)["octree_bytes"] for r in range(4)] == [per_rank] * 4
+    assert g.validate() and g.compute() and np.array_equal(g.read_hits(), ref_hits)
+    # dropping the attachments reaches every rank too: all of them render material 5 only
+    rc = vrc.lib.vrc_assign_octree_attachments(g._h, None, 0, None, 0)
+    assert rc == 0 and [g.memory_usage(r)["octree_bytes"] for r in range(4)] == [n_desc * 8] * 4
+    assert g.validate() and g.compute()
+    mats = g.read_hits()[..., 3]
+    assert set(np.unique(mats).tolist()) <= {0, 5}
+    # a new tree releases the ranks' own copies and fans out again (device-built this time)
+    info, _ = g.build_shell_terrain(10, 1, 2, 2)
+    assert all(g.memory_usage(r)["octree_bytes"] == info["n_descriptors"] * 8 for r in range(4))
+
+
+def test_hit_records_of_an_older_frame_are_not_handed_out(atlas):
+    """hit_records switched 1 -> 0: the buffer still holds the previous frame's records; read_hits must say NOT_READY
+    instead of returning them beside the new image (advisor finding, round 2)."""
+    s = scenes.floor_pillars()
+    dim, w, h = s["dim"], 128, 96
+    m = vrc.Map(dim, s["grid"])
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = s["lights"]
+    c = vrc.CLCaster()
+    assert c.init(0) and c.assign_octree(m.octree)
+    configure(c, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
+    assert c.validate() and c.compute()
+    hits = c.read_hits()
+    c._keep["cam"][1][0] += 1.5                                      # the next frame differs
+    assert c.add_to_settings_buffer("hit_records", "HIT_RECORDS", 0) and c.compute()
+    with pytest.raises(vrc.VrcError):
+        c.read_hits()
+    assert c.last_status == 2 and "hit_records is 0" in c.last_error()
+    assert c.overwrite_setting("hit_records", 1) and c.compute()
+    assert not np.array_equal(c.read_hits(), hits)
+
+
+def test_caller_supplied_destinations_are_checked(atlas):
+    """read_*(out=...) writes through a raw pointer: a wrong dtype, shape or a strided view must be refused."""
+    s = scenes.floor_pillars()
+    dim, w, h = s["dim"], 64, 48
+    m = vrc.Map(dim, s["grid"])
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = s["lights"]
+    c = vrc.CLCaster()
+    assert c.init(0) and c.assign_octree(m.octree)
+    configure(c, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
+    assert c.validate() and c.compute()
+    for bad in (np.zeros((h, w, 4), np.uint8), np.zeros((h, w, 3), np.float32), np.zeros((h, 2 * w, 4), np.float32)[:, ::2],
+                np.zeros((w, h, 4), np.float32)):
+        with pytest.raises(vrc.VrcError):
+            c.read_image(out=bad)
+    with pytest.raises(vrc.VrcError):
+        c.read_image_rgba8(out=np.zeros((h, w, 4), np.float32))
+    with pytest.raises(vrc.VrcError):
+        c.read_hits(out=np.zeros((h, w, 8), np.int64))
+    ok = np.zeros((h, w, 4), np.float32)
+    assert c.read_image(out=ok) is ok and ok.any()

@@ -54,7 +54,7 @@ class BuildInfo(C.Structure):
 
 class Memory(C.Structure):
     _fields_ = [("device", C.c_int32), ("rows", C.c_int32), ("viewport_bytes", C.c_uint64), ("image_bytes", C.c_uint64),
-                ("hit_bytes", C.c_uint64), ("octree_bytes", C.c_uint64), ("octree_shared", C.c_int32)]
+                ("hit_bytes", C.c_uint64), ("octree_bytes", C.c_uint64), ("octree_shared", C.c_int32), ("peer_access", C.c_int32)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -120,6 +120,7 @@ SIGNATURES = {
     "vrc_free": (None, [C.c_void_p]),
     "vrc_set_row_slice": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32]),
     "vrc_create_group": (C.c_int, [_i32p, C.c_int32, C.c_int32, C.POINTER(_H)]),
+    "vrc_create_group_ex": (C.c_int, [_i32p, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(_H)]),
     "vrc_group_size": (C.c_int, [_H, _i32p]),
     "vrc_pin_host_buffer": (C.c_int, [C.c_void_p, C.c_size_t]),
     "vrc_unpin_host_buffer": (C.c_int, [C.c_void_p]),
@@ -368,10 +369,11 @@ class CLCaster:
     def init(self, device_ordinal: int = 0) -> bool:
         return self._ok(lib.vrc_create(device_ordinal, C.byref(self._h)))
 
-    def init_group(self, device_ordinals, band_rows: int = 8) -> bool:
-        """One host thread, several GPUs (vrc_create_group): this object becomes rank 0 of a row-sliced group."""
+    def init_group(self, device_ordinals, band_rows: int = 8, own_copies: bool = False) -> bool:
+        """One host thread, several GPUs (vrc_create_group): this object becomes rank 0 of a row-sliced group.
+        own_copies (VRC_GROUP_OWN_COPIES): ranks on rank 0's GPU take the copy path of a rank on another GPU."""
         d = np.ascontiguousarray(device_ordinals, dtype=np.int32)
-        return self._ok(lib.vrc_create_group(_ptr(d, _i32p), d.size, band_rows, C.byref(self._h)))
+        return self._ok(lib.vrc_create_group_ex(_ptr(d, _i32p), d.size, band_rows, 1 if own_copies else 0, C.byref(self._h)))
 
     def group_size(self) -> int:
         n = C.c_int32()
@@ -524,11 +526,20 @@ class CLCaster:
         return self._ok(lib.vrc_set_row_slice(self._h, rank, world, band_rows))
 
     # -- output (replaces CLCaster::draw, CLCaster.cpp:330-332)
+    @staticmethod
+    def _check_out(out: np.ndarray, dtype, shape, what: str) -> None:
+        """A caller-supplied destination is written through a raw pointer: it must be exactly what the library assumes."""
+        if not isinstance(out, np.ndarray) or out.dtype != np.dtype(dtype) or out.shape != shape or not out.flags.c_contiguous \
+                or not out.flags.writeable:
+            raise VrcError(f"{what}: `out` must be a writable C-contiguous {np.dtype(dtype).name} array of shape {shape}, got "
+                           f"{getattr(out, 'dtype', type(out))} {getattr(out, 'shape', '')}")
+
     def read_image(self, out: Optional[np.ndarray] = None) -> np.ndarray:
         """The float4 frame.  A row-sliced handle fills only its own rows of `out` (pass the same array to every rank)."""
         w, h = self.viewport_size
         if out is None:
             out = np.empty((h, w, 4), dtype=np.float32)
+        self._check_out(out, np.float32, (h, w, 4), "read_image")
         if not self._ok(lib.vrc_read_image_f32(self._h, _ptr(out, _f32p), out.size)):
             raise VrcError(self.last_error())
         return out
@@ -537,6 +548,7 @@ class CLCaster:
         w, h = self.viewport_size
         if out is None:
             out = np.empty((h, w, 4), dtype=np.uint8)
+        self._check_out(out, np.uint8, (h, w, 4), "read_image_rgba8")
         if not self._ok(lib.vrc_read_image_rgba8(self._h, _ptr(out, _u8p), out.size)):
             raise VrcError(self.last_error())
         return out
@@ -545,6 +557,7 @@ class CLCaster:
         w, h = self.viewport_size
         if out is None:
             out = np.empty((h, w, 8), dtype=np.int32)
+        self._check_out(out, np.int32, (h, w, 8), "read_hits")
         if not self._ok(lib.vrc_read_hits(self._h, _ptr(out, _i32p), out.size)):
             raise VrcError(self.last_error())
         return out

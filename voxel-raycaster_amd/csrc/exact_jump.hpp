@@ -234,6 +234,9 @@ VRC_HD void jump_rows_build(bool want, bool live, uint32_t &rows, float tx, floa
 }
 VRC_HD uint32_t jump_table_entry(const uint32_t *tab, int stride, int pair, int32_t e) {
     const uint32_t row = (uint32_t)(e - kJumpFirstBinade);
+#ifdef VRC_JUMP_FAKE_TABLE   // (timing experiment only: no load, wrong tie counts)
+    return row < (uint32_t)kJumpBinades ? ((1u << 24) | (12345u + (uint32_t)pair)) : 0u;
+#endif
     return row < (uint32_t)kJumpBinades ? tab[(3 * (int)row + pair) * stride] : 0u;
 }
 

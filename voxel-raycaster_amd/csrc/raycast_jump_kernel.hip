@@ -135,7 +135,11 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
     };
     auto set_ray = [&](float x, float y, float z) {
         ox = x; oy = y; oz = z;
-        ivx = 1.0f / r.rdx; ivy = 1.0f / r.rdy; ivz = 1.0f / r.rdz;
+        // (a denormal component would give inf, and 0 * inf at a ray that starts exactly on a plane is NaN: the jump would
+        // have no minimum and make no progress.  Clamped to the largest float: such an axis crosses at t = 0 or never.)
+        ivx = fminf(fmaxf(1.0f / r.rdx, -3.402823466e38f), 3.402823466e38f);
+        ivy = fminf(fmaxf(1.0f / r.rdy, -3.402823466e38f), 3.402823466e38f);
+        ivz = fminf(fmaxf(1.0f / r.rdz, -3.402823466e38f), 3.402823466e38f);
     };
     // a restarted ray starts where the reference's restart arithmetic (:677-679, :700-702) puts it: hit_pos mirrored
     // inside the restart voxel (oracle/vrc_oracle.c jump_restart_ray)
@@ -283,8 +287,8 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
                 }
             } else if (mode == jShade) {
                 // delta_t and the intersection_t the hit block reads (:586-618), rebuilt from the exit (kept out of the
-                // traversal loop's registers: delta_t = |1 / ray_dir| is |iv| bit for bit)
-                r.dtx = fabsf(ivx); r.dty = fabsf(ivy); r.dtz = fabsf(ivz);
+                // traversal loop's registers; recomputed rather than taken from iv: iv is clamped, delta_t is not)
+                r.dtx = fabsf(1.0f / r.rdx); r.dty = fabsf(1.0f / r.rdy); r.dtz = fabsf(1.0f / r.rdz);
                 r.itx = r.fmx ? t_exit + r.dtx : ((float)(r.sx > 0 ? r.vx + 1 : r.vx) - ox) * ivx;
                 r.ity = r.fmy ? t_exit + r.dty : ((float)(r.sy > 0 ? r.vy + 1 : r.vy) - oy) * ivy;
                 r.itz = r.fmz ? t_exit + r.dtz : ((float)(r.sz > 0 ? r.vz + 1 : r.vz) - oz) * ivz;

@@ -46,6 +46,10 @@ struct vrc_caster {
     int8_t *d_map = nullptr; int32_t map_dim[3] = {0, 0, 0};
     uint64_t *d_desc = nullptr; uint64_t n_desc = 0; bool have_octree = false;
     bool owns_desc = true;                // false: a group rank on the same GPU as rank 0 shares rank 0's arrays
+    bool own_copy = false;                // group flag VRC_GROUP_OWN_COPIES: never share, always take the device-to-device copy path
+    int32_t peer_access = -1;             // -1 same GPU as rank 0 / rank 0 itself, 1 direct peer access enabled, 0 the runtime stages the copies
+    void *pinned_stage = nullptr; size_t pinned_stage_bytes = 0;   // read-back staging for a pageable destination (groups)
+    bool last_frame_wrote_hits = false;   // d_hits belongs to the last enqueued frame (setting hit_records was on)
     uint32_t *d_attach_lookup = nullptr; uint64_t *d_attach = nullptr; uint64_t n_attach = 0;
     float *d_viewport = nullptr; float *d_image = nullptr; int32_t *d_hits = nullptr; uint8_t *d_rgba8 = nullptr;
     uint32_t *d_jump_cache = nullptr; size_t jump_cache_bytes = 0;   // per-ray Euclid tables of the exact closed-form jumps (exact_jump.hpp)
@@ -247,9 +251,31 @@ int ensure_hits(vrc_caster *h) {
     return VRC_OK;
 }
 
-// device rows -> the caller's full-frame buffer, `bpp` bytes per pixel
-int copy_rows_out(vrc_caster *h, const void *dev, size_t bpp, void *host) {
+// Is this host address page-locked (hipHostMalloc / hipHostRegister)?  hipMemcpyAsync into pageable memory blocks the
+// calling thread copy by copy, which would serialise the tiles of a multi-GPU read-back.
+bool host_is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    (void)hipGetLastError();
+    return e == hipSuccess && a.type == hipMemoryTypeHost;
+}
+
+// device rows -> the caller's full-frame buffer, `bpp` bytes per pixel.  stage: copy into this rank's pinned staging
+// buffer instead (finish_rows_out moves them on after the stream has been waited for).
+int copy_rows_out(vrc_caster *h, const void *dev, size_t bpp, void *host, bool stage) {
     const size_t row = (size_t)h->width * bpp;
+    if (stage) {
+        const size_t bytes = row * (size_t)std::max(h->buffer_rows, 1);
+        if (h->pinned_stage_bytes < bytes) {
+            if (h->pinned_stage) (void)hipHostFree(h->pinned_stage);
+            h->pinned_stage = nullptr; h->pinned_stage_bytes = 0;
+            HIP_TRY(h, hipHostMalloc(&h->pinned_stage, bytes, hipHostMallocDefault));
+            h->pinned_stage_bytes = bytes;
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->pinned_stage, dev, row * (size_t)(h->sliced ? h->buffer_rows : h->height), hipMemcpyDeviceToHost, h->stream));
+        return VRC_OK;
+    }
     if (!h->sliced) {
         HIP_TRY(h, hipMemcpyAsync(host, dev, row * (size_t)h->height, hipMemcpyDeviceToHost, h->stream));
         return VRC_OK;
@@ -258,6 +284,13 @@ int copy_rows_out(vrc_caster *h, const void *dev, size_t bpp, void *host) {
         HIP_TRY(h, hipMemcpyAsync((char *)host + row * (size_t)r.y0, (const char *)dev + row * (size_t)r.b0, row * (size_t)r.n,
                                   hipMemcpyDeviceToHost, h->stream));
     return VRC_OK;
+}
+// second half of a staged read-back (after the rank's stream has been waited for): staging buffer -> the caller's frame
+void finish_rows_out(vrc_caster *h, size_t bpp, void *host) {
+    const size_t row = (size_t)h->width * bpp;
+    if (!h->sliced) { memcpy(host, h->pinned_stage, row * (size_t)h->height); return; }
+    for (const RowRun &r : row_runs(h, true))
+        memcpy((char *)host + row * (size_t)r.y0, (const char *)h->pinned_stage + row * (size_t)r.b0, row * (size_t)r.n);
 }
 
 int sync_one(vrc_caster *h) {
@@ -306,31 +339,48 @@ int vrc_create(int device_ordinal, vrc_caster **out) {
     return VRC_OK;
 }
 
-int vrc_create_group(const int32_t *device_ordinals, int32_t n, int32_t band_rows, vrc_caster **out) {
+int vrc_create_group_ex(const int32_t *device_ordinals, int32_t n, int32_t band_rows, uint32_t flags, vrc_caster **out) {
     if (!out || !device_ordinals || n < 1 || band_rows < vrc::kTileH || band_rows % vrc::kTileH) return VRC_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     vrc_caster *root = nullptr;
     int rc = vrc_create(device_ordinals[0], &root);
     if (rc != VRC_OK) return rc;
     root->tile_rank = 0; root->tile_world = n; root->band_rows = band_rows; root->sliced = n > 1;
+    std::string notes;
     for (int32_t r = 1; r < n; r++) {
         vrc_caster *q = nullptr;
         rc = vrc_create(device_ordinals[r], &q);
         if (rc != VRC_OK) { vrc_destroy(root); return rc; }
         q->tile_rank = r; q->tile_world = n; q->band_rows = band_rows; q->sliced = true; q->is_peer = true;
+        q->own_copy = (flags & VRC_GROUP_OWN_COPIES) != 0;
         root->peers.push_back(q);
         if (q->device != root->device) {                       // SVO fan-out goes device to device over xGMI
             int can = 0;
+            q->peer_access = 0;
             if (hipDeviceCanAccessPeer(&can, q->device, root->device) == hipSuccess && can) {
                 (void)hipSetDevice(q->device);
-                (void)hipDeviceEnablePeerAccess(root->device, 0);
-                (void)hipGetLastError();
+                const hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
+                if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) q->peer_access = 1;
+            }
+            (void)hipGetLastError();
+            if (!q->peer_access) {
+                char buf[160];
+                snprintf(buf, sizeof(buf), "rank %d: no direct peer access from GPU %d to GPU %d, tree copies are staged by the runtime; ",
+                         r, q->device, root->device);
+                notes += buf;
             }
         }
     }
     (void)hipSetDevice(root->device);
+    root->error = notes;                   // not a failure: vrc_last_error right after creation tells which ranks fell back
     *out = root;
     return VRC_OK;
+}
+
+int vrc_create_group(const int32_t *device_ordinals, int32_t n, int32_t band_rows, vrc_caster **out) {
+    // VRC_GROUP_OWN_COPIES=1 in the environment: rehearse the distinct-GPU code paths on a box with one GPU
+    const char *env = getenv("VRC_GROUP_OWN_COPIES");
+    return vrc_create_group_ex(device_ordinals, n, band_rows, (env && env[0] == '1') ? VRC_GROUP_OWN_COPIES : 0u, out);
 }
 
 int vrc_group_size(const vrc_caster *h, int32_t *n) {
@@ -352,6 +402,7 @@ int vrc_destroy(vrc_caster *h) {
     release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_jump_cache); release(h->d_atlas);
     release(h->d_partials); release(h->d_counters); release(h->d_frame);
     if (h->wd_flag) (void)hipHostFree(h->wd_flag);
+    if (h->pinned_stage) (void)hipHostFree(h->pinned_stage);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return VRC_OK;
@@ -396,7 +447,7 @@ int fan_out_tree(vrc_caster *h) {
     for (size_t i = 0; i < h->peers.size(); i++) {
         vrc_caster *q = h->peers[i];
         release_tree(q);
-        if (q->device == h->device) {
+        if (q->device == h->device && !q->own_copy) {
             q->d_desc = h->d_desc; q->d_attach_lookup = h->d_attach_lookup; q->d_attach = h->d_attach;
             q->owns_desc = false;
         } else {
@@ -416,7 +467,7 @@ int fan_out_tree(vrc_caster *h) {
         if (rc != VRC_OK) return rc;
     }
     for (vrc_caster *q : h->peers)
-        if (q->device != h->device) { HIP_TRY(h, hipSetDevice(q->device)); HIP_TRY(h, hipStreamSynchronize(q->stream)); }
+        if (q->owns_desc) { HIP_TRY(h, hipSetDevice(q->device)); HIP_TRY(h, hipStreamSynchronize(q->stream)); }
     HIP_TRY(h, hipSetDevice(h->device));
     return VRC_OK;
 }
@@ -451,15 +502,24 @@ int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->have_octree) return fail(h, VRC_ERR_NOT_READY, "assign_octree_attachments: assign the octree first");
     HIP_TRY(h, hipSetDevice(h->device));
-    for (vrc_caster *q : h->peers)
-        if (!q->owns_desc) { q->d_attach_lookup = nullptr; q->d_attach = nullptr; q->n_attach = 0; }
-    release(h->d_attach_lookup); release(h->d_attach);
-    h->n_attach = 0; h->validated = false;
-    if (lookup && n_lookup && attachments && n_attachments) {
+    // the arguments are checked before anything is touched: a rejected call leaves every rank as it was
+    const bool have = lookup && n_lookup && attachments && n_attachments;
+    if (have) {
         if (n_lookup != h->n_desc)
             return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_attachments: lookup must have one entry per descriptor");
         if (!lookup_in_range(lookup, (size_t)n_lookup, n_attachments))
             return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_attachments: a lookup entry points past the attachment buffer");
+    }
+    // from here on every rank drops its old buffers first, so that a device failure half-way can never leave two ranks
+    // of one frame with different materials (ranks that share rank 0's arrays just forget the pointers)
+    for (vrc_caster *q : h->peers) {
+        if (q->owns_desc) { (void)hipSetDevice(q->device); release(q->d_attach_lookup); release(q->d_attach); }
+        q->d_attach_lookup = nullptr; q->d_attach = nullptr; q->n_attach = 0; q->validated = false;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    release(h->d_attach_lookup); release(h->d_attach);
+    h->n_attach = 0; h->validated = false;
+    if (have) {
         HIP_TRY(h, hipMalloc((void **)&h->d_attach_lookup, n_lookup * sizeof(uint32_t)));
         HIP_TRY(h, hipMemcpy(h->d_attach_lookup, lookup, n_lookup * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMalloc((void **)&h->d_attach, n_attachments * sizeof(uint64_t)));
@@ -467,23 +527,18 @@ int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_
         h->n_attach = n_attachments;
     }
     if (h->peers.empty()) return VRC_OK;
-    // ranks on other GPUs own their copy of the descriptors: only the attachment buffers change
+    // ranks with their own copy of the descriptors: only the attachment buffers change
     for (vrc_caster *q : h->peers) {
-        if (q->device == h->device) {
+        if (!q->owns_desc) {
             q->d_attach_lookup = h->d_attach_lookup; q->d_attach = h->d_attach; q->n_attach = h->n_attach;
-        } else {
+        } else if (h->d_attach_lookup && h->d_attach) {
             HIP_TRY(h, hipSetDevice(q->device));
-            release(q->d_attach_lookup); release(q->d_attach);
-            q->n_attach = 0;
-            if (h->d_attach_lookup && h->d_attach) {
-                HIP_TRY(h, hipMalloc((void **)&q->d_attach_lookup, h->n_desc * sizeof(uint32_t)));
-                HIP_TRY(h, hipMalloc((void **)&q->d_attach, h->n_attach * sizeof(uint64_t)));
-                HIP_TRY(h, hipMemcpyPeer(q->d_attach_lookup, q->device, h->d_attach_lookup, h->device, h->n_desc * sizeof(uint32_t)));
-                HIP_TRY(h, hipMemcpyPeer(q->d_attach, q->device, h->d_attach, h->device, h->n_attach * sizeof(uint64_t)));
-                q->n_attach = h->n_attach;
-            }
+            HIP_TRY(h, hipMalloc((void **)&q->d_attach_lookup, h->n_desc * sizeof(uint32_t)));
+            HIP_TRY(h, hipMalloc((void **)&q->d_attach, h->n_attach * sizeof(uint64_t)));
+            HIP_TRY(h, hipMemcpyPeer(q->d_attach_lookup, q->device, h->d_attach_lookup, h->device, h->n_desc * sizeof(uint32_t)));
+            HIP_TRY(h, hipMemcpyPeer(q->d_attach, q->device, h->d_attach, h->device, h->n_attach * sizeof(uint64_t)));
+            q->n_attach = h->n_attach;
         }
-        q->validated = false;
     }
     HIP_TRY(h, hipSetDevice(h->device));
     return VRC_OK;
@@ -777,6 +832,7 @@ int compute_async_one(vrc_caster *h) {
         if (rc != VRC_OK) return rc;
         p.hits = h->d_hits;
     }
+    h->last_frame_wrote_hits = p.hits != nullptr;
     p.viewport = h->d_viewport; p.image = h->d_image;
     p.atlas = h->d_atlas; p.atlas_w = h->atlas_w; p.atlas_h = h->atlas_h;
     p.tiles_x = h->atlas_w / h->tile_w; p.tiles_y = h->atlas_h / h->tile_h;
@@ -876,17 +932,26 @@ int compute_async_one(vrc_caster *h) {
 
 // what read_image / read_hits / read_image_rgba8 have in common: every rank copies its rows into the caller's frame
 // (asynchronously, each on its own stream), then all ranks are waited for
+// A group reading into pageable memory stages every rank's tile through its own pinned buffer, so that the n copies
+// still run side by side (a pageable hipMemcpyAsync blocks the host thread); a single handle copies directly.
 template <class Enqueue>
-int gather_rows(vrc_caster *h, Enqueue enqueue) {
-    int rc = enqueue(h);
+int gather_rows(vrc_caster *h, void *host, size_t bpp, Enqueue enqueue) {
+    const bool stage = !h->peers.empty() && !host_is_pinned(host);
+    int rc = enqueue(h, stage);
     if (rc != VRC_OK) return rc;
     for (size_t i = 0; i < h->peers.size(); i++) {
-        rc = enqueue(h->peers[i]);
+        rc = enqueue(h->peers[i], stage);
         if (rc != VRC_OK) return fail(h, rc, "rank %zu: %s", i + 1, h->peers[i]->error.c_str());
     }
     rc = sync_one(h);
     if (rc != VRC_OK) return rc;
-    FOR_PEERS(h, sync_one(q));
+    if (stage) finish_rows_out(h, bpp, host);
+    for (size_t pi = 0; pi < h->peers.size(); pi++) {
+        vrc_caster *q = h->peers[pi];
+        rc = sync_one(q);
+        if (rc != VRC_OK) return fail(h, rc, "rank %zu: %s", pi + 1, q->error.c_str());
+        if (stage) finish_rows_out(q, bpp, host);
+    }
     HIP_TRY(h, hipSetDevice(h->device));
     return VRC_OK;
 }
@@ -925,9 +990,9 @@ int vrc_read_image_f32(vrc_caster *h, float *rgba, size_t n_floats) {
     if (!h || !rgba) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_image) return fail(h, VRC_ERR_NOT_READY, "read_image: no viewport");
     if (n_floats < (size_t)4 * h->width * h->height) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_image_f32: buffer too small");
-    return gather_rows(h, [rgba](vrc_caster *q) -> int {
+    return gather_rows(h, rgba, 16, [rgba](vrc_caster *q, bool stage) -> int {
         HIP_TRY(q, hipSetDevice(q->device));
-        return copy_rows_out(q, q->d_image, 16, rgba);
+        return copy_rows_out(q, q->d_image, 16, rgba, stage);
     });
 }
 
@@ -937,24 +1002,27 @@ int vrc_read_image_rgba8(vrc_caster *h, uint8_t *rgba, size_t n_bytes) {
     if (!h || !rgba) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_image) return fail(h, VRC_ERR_NOT_READY, "read_image: no viewport");
     if (n_bytes < (size_t)4 * h->width * h->height) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_image_rgba8: buffer too small");
-    return gather_rows(h, [rgba](vrc_caster *q) -> int {
+    return gather_rows(h, rgba, 4, [rgba](vrc_caster *q, bool stage) -> int {
         HIP_TRY(q, hipSetDevice(q->device));
         const size_t npix = (size_t)q->width * (size_t)std::max(q->buffer_rows, 1);
         if (!q->d_rgba8) HIP_TRY(q, hipMalloc((void **)&q->d_rgba8, 4 * npix));
         HIP_TRY(q, vrc::launch_pack_rgba8(q->d_image, q->d_rgba8, npix, q->stream));
-        return copy_rows_out(q, q->d_rgba8, 4, rgba);
+        return copy_rows_out(q, q->d_rgba8, 4, rgba, stage);
     });
 }
 
 int vrc_read_hits(vrc_caster *h, int32_t *hits, size_t n_int32) {
     if (!h || !hits) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_viewport) return fail(h, VRC_ERR_NOT_READY, "read_hits: no viewport");
-    if (!h->d_hits) return fail(h, VRC_ERR_NOT_READY, "read_hits: no hit records (setting hit_records is 0, or no frame computed yet)");
+    // the records must belong to the frame the image belongs to: with hit_records switched off since, the buffer still
+    // holds an older frame's records
+    if (!h->d_hits || !h->last_frame_wrote_hits)
+        return fail(h, VRC_ERR_NOT_READY, "read_hits: no hit records (setting hit_records is 0, or no frame computed yet)");
     if (n_int32 < (size_t)8 * h->width * h->height) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_hits: buffer too small");
-    return gather_rows(h, [hits](vrc_caster *q) -> int {
+    return gather_rows(h, hits, 32, [hits](vrc_caster *q, bool stage) -> int {
         HIP_TRY(q, hipSetDevice(q->device));
-        if (!q->d_hits) return fail(q, VRC_ERR_NOT_READY, "read_hits: no hit records");
-        return copy_rows_out(q, q->d_hits, 32, hits);
+        if (!q->d_hits || !q->last_frame_wrote_hits) return fail(q, VRC_ERR_NOT_READY, "read_hits: no hit records");
+        return copy_rows_out(q, q->d_hits, 32, hits, stage);
     });
 }
 
@@ -991,6 +1059,7 @@ int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out) {
     out->hit_bytes = q->d_hits ? 32 * npix : 0;
     out->octree_bytes = q->d_desc ? q->n_desc * 8 + (q->d_attach_lookup ? q->n_desc * 4 + std::max<uint64_t>(q->n_attach, 1) * 8 : 0) : 0;
     out->octree_shared = q->owns_desc ? 0 : 1;
+    out->peer_access = q->peer_access;
     return VRC_OK;
 }
 
