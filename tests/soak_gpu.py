@@ -18,10 +18,10 @@ from oracle import orc  # noqa: E402
 from test_parity_gpu import make_caster  # noqa: E402
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    sc = bench.build_scene(int(sys.argv[3]) if len(sys.argv) > 3 else 12)
+def run(budget=300.0, seed=1, depth=12, sc=None):
+    """Returns (mismatching bands, poses, rows compared).  tests/test_round3_gpu.py runs a 10-second slice of it."""
+    rng = np.random.default_rng(seed)
+    sc = sc or bench.build_scene(depth)
     dim, w, h = sc["dim"], 512, 288
     t0, poses, rows, bad, by_mode = time.time(), 0, 0, 0, [0, 0]
     while time.time() - t0 < budget:
@@ -70,8 +70,9 @@ def main():
         del c
     print(f"soak: {poses} poses ({by_mode[0]} exact, {by_mode[1]} mode B), {rows} rows of {w} pixels compared, {bad} mismatching bands, "
           f"{time.time() - t0:.0f} s")
-    return 1 if bad else 0
+    return bad, poses, rows
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(1 if run(float(sys.argv[1]) if len(sys.argv) > 1 else 300.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                      int(sys.argv[3]) if len(sys.argv) > 3 else 12)[0] else 0)

@@ -20,9 +20,10 @@ import test_reference_pin_gpu as pin  # noqa: E402
 import voxel_raycaster_amd as vrc  # noqa: E402
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def run(budget=300.0, seed=1):
+    """Returns (frames with a difference in what the primary ray decides, frames, statistics).  tests/test_round3_gpu.py
+    runs a 10-second slice of it."""
+    rng = np.random.default_rng(seed)
     probe = C.CDLL(os.path.join(pin.REF, "libref_probe.so"))
     probe.ref_probe_last_error.restype = C.c_char_p
     atlas = vrc.synthetic_atlas()
@@ -56,8 +57,8 @@ def main():
           f"final step count equal {totals.get('same_steps', 0) / n:.6f}, alpha equal {totals.get('alpha_same', 0) / n:.6f}, "
           f"rgb within 1e-5 {totals.get('rgb_1e-5', 0) / n:.6f}, within 1e-4 {totals.get('rgb_1e-4', 0) / n:.6f} "
           f"(worst {totals.get('worst_rgb', 0.0):.2e}); {time.time() - t0:.0f} s")
-    return 1 if failures else 0
+    return failures, frames, totals
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(1 if run(float(sys.argv[1]) if len(sys.argv) > 1 else 300.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)[0] else 0)

@@ -1,0 +1,113 @@
+"""GPU suite (-m gpu), round 3: slices of the two soaks inside the suite, the reference builder's own buffer layout
+through both branches, the exact closed-form jumps on every kind of frame."""
+import numpy as np
+import pytest
+
+import scenes
+import voxel_raycaster_amd as vrc
+from oracle import orc
+from test_parity_gpu import assert_same, make_caster
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ soak slices (fixed seeds: the driver runs them)
+def test_soak_slice_product_against_the_oracle():
+    """Ten seconds of tests/soak_gpu.py with a fixed seed: random camera poses / light sets / step caps in the depth-12
+    bench scene, exact mode (closed-form jumps on, the default at this depth) and mode B, single handles and 3-rank
+    groups, device RGBA8 pack -- whole 8-row tile bands against the oracle, bit for bit."""
+    import soak_gpu
+    bad, poses, rows = soak_gpu.run(budget=10.0, seed=20261002, depth=12)
+    assert poses >= 3 and rows >= 72
+    assert bad == 0
+
+
+def test_soak_slice_reference_kernel_against_the_oracle():
+    """Ten seconds of tests/soak_reference_gpu.py with a fixed seed: the reference's own raycaster kernel on the MI355X
+    (two image builtins redirected) against the oracle on random poses in the probe scenes."""
+    import os
+    import test_reference_pin_gpu as pin
+    if not os.path.exists(os.path.join(pin.REF, "ref_raycaster_gfx950_strict.co")):
+        pytest.fail("oracle/_ref/ is missing: build it with `make -C oracle _ref` where /root/reference exists")
+    import soak_reference_gpu
+    failures, frames, totals = soak_reference_gpu.run(budget=10.0, seed=20261002)
+    n = max(totals.get("shaded", 0), 1)
+    print(f"\nreference soak slice: {frames} frames, shaded pixels {totals.get('shaded', 0)}, rgb within 1e-5 "
+          f"{totals.get('rgb_1e-5', 0) / n:.6f}, within 1e-4 {totals.get('rgb_1e-4', 0) / n:.6f}")
+    assert frames >= 20 and failures == 0
+    assert totals.get("rgb_1e-5", 0) / n >= 0.999
+
+
+# ------------------------------------------------------------------ the array a reference host would pass
+@pytest.mark.parametrize("dim,density,seed", [(64, 0.5, 7), (128, 0.02, 5)], ids=["64^3-half-full", "128^3-sparse"])
+def test_strict_reference_buffer_through_both_branches(dim, density, seed, atlas):
+    """The nearest thing to consuming the reference builder's output: a tree in `strict_reference` layout -- the fixed
+    100 000-entry buffer filled from the end (include/map/Octree.h:29), all-ones page-header slots every 0x8000 entries
+    and far pointers (src/map/Octree.cpp:251-315), including the builder's own far-pointer quirks -- rendered through
+    the SVO branch and, with its dense twin, through the array branch; both equal the oracle and each other."""
+    rng = np.random.default_rng(seed)
+    grid = (rng.random(dim ** 3) < density).astype(np.int8) * 5
+    if dim == 64:
+        grid.reshape(dim, dim, dim)[dim // 2 - 2: dim // 2 + 2, :, :] = 0      # a corridor to look along
+    o = vrc.Octree.Generate(grid, dim, buffer_size=100000, strict_reference=True)
+    buf = o.descriptor_buffer
+    assert buf.size == 100000
+    far = int(((buf >> np.uint64(15)) & np.uint64(1))[buf != np.uint64(0xFFFFFFFFFFFFFFFF)].sum())
+    headers = int((buf == np.uint64(0xFFFFFFFFFFFFFFFF)).sum())
+    print(f"\nstrict tree {dim}^3: root at {o.root_index}, {int((buf != 0).sum())} non-zero slots, {far} far pointers, {headers} page headers")
+    assert headers > 0 and (far > 0 or dim == 64)                            # the layout features this test is about
+    # the oracle's builder produces the same array bit for bit (two independent implementations of Octree.cpp)
+    obuf, oroot = orc.octree_generate(grid, dim)
+    assert oroot == o.root_index and np.array_equal(obuf, buf)
+    w, h, md = 160, 120, 3 * dim
+    cam_pos, cam_dir = (dim / 2 + 0.31, 1.37, dim / 2 + 0.43), (1.45, 1.5708)
+    li = np.zeros((1, 10), dtype=np.float32)
+    li[0] = [0.01, 0.01, 0.01, 0.2, dim * 0.8, dim * 0.2, dim * 0.9, 0, 0, -1]
+    frames = []
+    for using_octree in (0, 1):
+        c = make_caster(o, dim, using_octree, cam_dir, cam_pos, li, atlas, w, h, md, grid=grid)
+        assert c.compute(), c.last_error()
+        oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas, tile_dim=(16, 16),
+                                        descriptors=buf, root_index=o.root_index, octree_dim=dim, using_octree=using_octree,
+                                        grid=grid, max_distance=md)
+        img, hits = c.read_image(), c.read_hits()
+        assert_same(img, hits, c.counters(), oimg, ohits, octr)
+        frames.append((img, hits))
+    assert (frames[0][1][..., 3] == 5).sum() > 1000
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
+    assert np.array_equal(frames[0][1][..., :7], frames[1][1][..., :7])       # (the descriptor-read count differs by construction)
+
+
+# ------------------------------------------------------------------ exact closed-form jumps: identical frames
+@pytest.mark.parametrize("depth,lights,k", [(10, 1, 8), (12, 1, 96), (12, 4, 32), (13, 2, 96)],
+                         ids=["d10-K8", "d12-default", "d12-4lights-K32", "d13-2lights"])
+def test_exact_jumps_leave_the_frame_bit_identical(depth, lights, k):
+    """exact_jump.hpp inside the step kernel: the frame -- image, hit records, every counter -- with jumps is the frame
+    without them, on whole 1080p frames (primary + shadow rays, multi-light relighting, mirrors via attachments at depth
+    10), whatever the threshold; and the jumps really ran (the frame with them is faster at depth >= 12)."""
+    import bench
+    sc = bench.build_scene(depth)
+    tree = sc["octree"]
+    if depth == 10 and tree.attachment_lookup is None:
+        tree.attach_materials_procedural(depth, seed=1, mirror_period=64)
+    c = bench.make_caster(sc, 1920, 1080, 0, light_count=lights)
+    assert c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 1 << 24)
+    times = {}
+    frames = {}
+    for setting in (1 << 24, k):
+        assert c.overwrite_setting("jump_min_run", setting)
+        for _ in range(2):
+            assert c.compute(), c.last_error()
+        c.timing_reset()
+        for _ in range(4):
+            assert c.compute(), c.last_error()
+        n, ms = c.timing()
+        times[setting] = ms / n
+        frames[setting] = (c.read_image(), c.read_hits(), c.counters())
+    a, b = frames[1 << 24], frames[k]
+    assert a[2] == b[2]
+    assert np.array_equal(a[1], b[1]), f"{int((a[1] != b[1]).any(-1).sum())} pixels differ in hit records"
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    print(f"\ndepth {depth}, {lights} light(s): {times[1 << 24]:.3f} ms stepping, {times[k]:.3f} ms with jumps (jump_min_run {k})")
+    if depth >= 12 and k >= 64:
+        assert times[k] < times[1 << 24]
