@@ -279,7 +279,8 @@ int vrc_scene_shell_terrain_dense(uint32_t depth, uint64_t seed, int32_t thickne
  * output the reference drops in the empty Map::ApplyHeightmap (:140-142).  height: uint8[dim*dim] =
  * clamp(value, 0, dim) like :241; corner_seed is the reference's `rand() % 10 + 55` (:160; 58 with an unseeded glibc).
  * grid (optional, int8[dim^3], x + dim*(y + dim*z)): what ApplyHeightmap was meant to do -- material 5 at and
- * below the height of each column, 0 above (our definition; the reference has none).                            */
+ * below the height of each column, 0 above (our definition; the reference has none).  dim <= 4096 with a grid,
+ * <= 16384 without (then feed the heights to vrc_build_heightfield: no dense grid anywhere).                    */
 int vrc_scene_diamond_square(uint32_t dim, double corner_seed, uint8_t *height, int8_t *grid);
 
 /* The same scene with its knobs exposed: octave_floor = log2 of the finest noise cell (2 in vrc_scene_shell_terrain),
@@ -313,6 +314,17 @@ typedef struct vrc_build_info {
 int vrc_build_shell_terrain(vrc_caster *h, uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor,
                             uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
                             int32_t *probe_lohi, vrc_build_info *info);
+/* The same builder for ANY column scene: column (x,y) is solid for lo[x + dim*y] <= z <= hi[x + dim*y] (uint16[dim*dim]
+ * each; lo == NULL: solid from z = 0 up).  This is Octree::Generate (src/map/Octree.cpp:13-43) for terrains -- e.g. the
+ * reference's own diamond-square height field, Map::GenerateHeightBitmap (src/map/Map.cpp:144-262,
+ * vrc_scene_diamond_square) -- without the dense char[D^3] grid: only the 2-D field crosses PCIe, the tree is built in
+ * the handle's HBM and installed as the octree.  Bit-identical to vrc_octree_from_columns(..., VRC_LAYOUT_NO_PAGE_HEADERS).
+ * validate_samples as above (tree point queries against the columns).                                               */
+int vrc_build_heightfield(vrc_caster *h, uint32_t depth, const uint16_t *hi, const uint16_t *lo, uint32_t flags,
+                          uint64_t validate_samples, vrc_build_info *info);
+/* Host twin of vrc_build_heightfield (sequential emitter, depth <= 13): the array to compare the device build with. */
+int vrc_octree_from_columns(uint32_t depth, const uint16_t *hi, const uint16_t *lo, uint32_t layout, uint64_t **descriptors,
+                            uint64_t *n_descriptors, uint64_t *root_index);
 /* Read descriptors [first, first + count) of the resident octree back to the host (tests, tools). */
 int vrc_read_descriptors(vrc_caster *h, uint64_t first, uint64_t count, uint64_t *out);
 int vrc_octree_size(vrc_caster *h, uint64_t *n_descriptors, uint64_t *root_index);

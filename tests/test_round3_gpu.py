@@ -111,3 +111,60 @@ def test_exact_jumps_leave_the_frame_bit_identical(depth, lights, k):
     print(f"\ndepth {depth}, {lights} light(s): {times[1 << 24]:.3f} ms stepping, {times[k]:.3f} ms with jumps (jump_min_run {k})")
     if depth >= 12 and k >= 64:
         assert times[k] < times[1 << 24]
+
+
+# ------------------------------------------------------------------ device builder for any column scene (SURVEY 8f-4 at scale)
+@pytest.mark.parametrize("depth", [8, 9, 10])
+def test_device_heightfield_builder_equals_the_host_emitter(depth):
+    """vrc_build_heightfield on the reference's diamond-square height field (Map::GenerateHeightBitmap, Map.cpp:144-262):
+    the array built in HBM is bit-identical to the sequential host emitter's (vrc_octree_from_columns), with solid
+    columns (lo = 0) and with a shell (lo = hi - 5); the device-side Octree::Validate finds no mismatch."""
+    dim = 1 << depth
+    height, _ = vrc.diamond_square(dim, want_grid=False)
+    hi = np.minimum(height.astype(np.uint16), dim - 1)
+    for lo in (None, np.maximum(hi.astype(np.int32) - 5, 0).astype(np.uint16)):
+        host = vrc.octree_from_columns(depth, hi, lo, layout=2)
+        c = vrc.CLCaster()
+        assert c.init(0)
+        info = c.build_heightfield(depth, hi, lo, validate_samples=1 << 20)
+        assert info["validate_mismatches"] == 0 and info["validate_samples"] == 1 << 20
+        n, root = c.octree_size()
+        assert n == host.descriptor_buffer.size == info["n_descriptors"] and root == host.root_index
+        assert np.array_equal(c.read_descriptors(), host.descriptor_buffer)
+    with pytest.raises(vrc.VrcError):
+        c.build_heightfield(depth, np.full((dim, dim), dim, dtype=np.uint16))        # a column taller than the map
+
+
+def test_depth13_diamond_square_terrain_against_the_oracle(atlas):
+    """f4 past the dense-grid limit: the 8192^2 diamond-square height field (67 M mt19937 draws on the host, in the
+    reference's order) built into an SVO on the device -- no 8192^3 grid anywhere -- and rendered at 1080p; sampled rows
+    bit-exact against the oracle, which reads the descriptors it needs from the GPU page by page."""
+    depth = 13
+    dim = 1 << depth
+    height, _ = vrc.diamond_square(dim, want_grid=False)
+    hi = np.minimum(height.astype(np.uint16), dim - 1)
+    c = vrc.CLCaster()
+    assert c.init(0)
+    info = c.build_heightfield(depth, hi, None, validate_samples=1 << 22)
+    assert info["validate_mismatches"] == 0
+    print(f"\ndepth-13 diamond-square terrain: {info['n_descriptors'] / 1e6:.1f} M descriptors built in {info['seconds_total']:.2f} s "
+          f"(host tables {info['host_bytes'] / 1e6:.0f} MB)")
+    w, h, md = 1920, 1080, 3 * dim
+    cam_pos = np.array([dim / 2 + 0.37, dim / 8 + 0.41, float(height.max()) + 40.29], dtype=np.float32)
+    cam_dir = np.array([1.75, 1.5708], dtype=np.float32)
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[0] = [0.01, 0.01, 0.01, 0.2, dim / 2, dim / 3, 400.0, -1.0, -1.0, -1.5]
+    ok = (c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c.add_to_settings_buffer("using_octree", "OCTENABLED", 0)
+          and c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", md) and c.assign_camera(cam_dir, cam_pos)
+          and c.create_viewport(w, h) and c.assign_lights(li) and c.create_texture_atlas(atlas, (16, 16)) and c.validate() and c.compute())
+    assert ok, c.last_error()
+    img, hits, ctr = c.read_image(), c.read_hits(), c.counters()
+    assert (hits[..., 3] == 5).sum() > w * h // 4 and ctr["shadow_rays"] > w * h // 4
+    n, root = c.octree_size()
+    paged = orc.PagedDescriptors(n, c.read_descriptors)
+    for y0 in range(37, h, 131):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=li, atlas=atlas, tile_dim=(16, 16),
+                                     descriptors=paged, root_index=root, octree_dim=dim, using_octree=0, max_distance=md,
+                                     rows=(y0, y0 + 1), threads=16)
+        assert np.array_equal(hits[y0], ohits[y0]), f"row {y0}: {int((hits[y0] != ohits[y0]).any(-1).sum())} pixels differ"
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))

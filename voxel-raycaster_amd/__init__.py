@@ -117,6 +117,9 @@ SIGNATURES = {
                                   C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(_u64p), _u64p]),
     "vrc_assign_octree_file": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_uint32)]),
     "vrc_scene_diamond_square": (C.c_int, [C.c_uint32, C.c_double, _u8p, _i8p]),
+    "vrc_build_heightfield": (C.c_int, [_H, C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_uint32, C.c_uint64,
+                                       C.POINTER(BuildInfo)]),
+    "vrc_octree_from_columns": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_uint32, C.POINTER(_u64p), _u64p, _u64p]),
     "vrc_free": (None, [C.c_void_p]),
     "vrc_set_row_slice": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32]),
     "vrc_create_group": (C.c_int, [_i32p, C.c_int32, C.c_int32, C.POINTER(_H)]),
@@ -302,6 +305,23 @@ def diamond_square(dim: int, corner_seed: float = 58.0, want_grid: bool = True):
     return height, grid
 
 
+def octree_from_columns(depth: int, hi: np.ndarray, lo: Optional[np.ndarray] = None, layout: int = 2) -> "Octree":
+    """vrc_octree_from_columns: the host twin of CLCaster.build_heightfield (layout 2 = VRC_LAYOUT_NO_PAGE_HEADERS, the
+    layout the device builder emits)."""
+    dim = 1 << depth
+    hi = np.ascontiguousarray(hi, dtype=np.uint16).reshape(dim, dim)
+    lo = None if lo is None else np.ascontiguousarray(lo, dtype=np.uint16).reshape(dim, dim)
+    out, n, root = _u64p(), C.c_uint64(), C.c_uint64()
+    u16 = C.POINTER(C.c_uint16)
+    rc = lib.vrc_octree_from_columns(depth, _ptr(hi, u16), _ptr(lo, u16) if lo is not None else None, layout,
+                                     C.byref(out), C.byref(n), C.byref(root))
+    if rc != 0:
+        raise VrcError(f"vrc_octree_from_columns: {STATUS.get(rc, rc)}")
+    arr = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
+    lib.vrc_free(out)
+    return Octree(arr, root.value, dim)
+
+
 def pin_host_buffer(a: np.ndarray) -> None:
     """vrc_pin_host_buffer: page-lock a caller-owned frame buffer so that read_image*(out=a) copies by DMA without a
     staging pass (the reference shares a GL texture instead, src/CLCaster.cpp:278-296)."""
@@ -402,6 +422,21 @@ class CLCaster:
         if not self._ok(rc):
             raise VrcError(self.last_error())
         return info.as_dict(), plh
+
+    def build_heightfield(self, depth: int, hi: np.ndarray, lo: Optional[np.ndarray] = None, count_only: bool = False,
+                          validate_samples: int = 0) -> dict:
+        """vrc_build_heightfield: the SVO of a column scene (solid for lo <= z <= hi, uint16[dim, dim] each; lo None:
+        from z = 0 up) built in HBM from the 2-D field alone.  Returns the build info; raises on failure."""
+        dim = 1 << depth
+        hi = np.ascontiguousarray(hi, dtype=np.uint16).reshape(dim, dim)
+        lo = None if lo is None else np.ascontiguousarray(lo, dtype=np.uint16).reshape(dim, dim)
+        info = BuildInfo()
+        u16 = C.POINTER(C.c_uint16)
+        rc = lib.vrc_build_heightfield(self._h, depth, _ptr(hi, u16), _ptr(lo, u16) if lo is not None else None,
+                                       BUILD_COUNT_ONLY if count_only else 0, validate_samples, C.byref(info))
+        if not self._ok(rc):
+            raise VrcError(self.last_error())
+        return info.as_dict()
 
     def octree_size(self):
         n, root = C.c_uint64(), C.c_uint64()

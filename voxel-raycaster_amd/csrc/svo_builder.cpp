@@ -237,6 +237,30 @@ struct ShellSource {
                 }
         }
     }
+    // the same from caller-supplied columns: column (x,y) is solid for lo <= z <= hi (lo == nullptr: from z = 0 up)
+    void init_columns(uint32_t depth, const uint16_t *hi, const uint16_t *lo) {
+        dim = 1LL << depth;
+        levels = (int)depth + 1;
+        lo_min.assign(levels, {});
+        hi_max.assign(levels, {});
+        lo_min[0].resize((size_t)(dim * dim));
+        hi_max[0].resize((size_t)(dim * dim));
+        for (size_t i = 0; i < lo_min[0].size(); i++) { hi_max[0][i] = hi[i]; lo_min[0][i] = lo ? lo[i] : 0; }
+        build_mips();
+    }
+    void build_mips() {
+        for (int l = 1; l < levels; l++) {
+            const int64_t d = dim >> l, pd = dim >> (l - 1);
+            lo_min[l].resize((size_t)(d * d));
+            hi_max[l].resize((size_t)(d * d));
+            for (int64_t y = 0; y < d; y++)
+                for (int64_t x = 0; x < d; x++) {
+                    const size_t a = (size_t)(2 * x + pd * (2 * y)), b = a + 1, c = a + (size_t)pd, e = c + 1;
+                    lo_min[l][(size_t)(x + d * y)] = std::min(std::min(lo_min[l - 1][a], lo_min[l - 1][b]), std::min(lo_min[l - 1][c], lo_min[l - 1][e]));
+                    hi_max[l][(size_t)(x + d * y)] = std::max(std::max(hi_max[l - 1][a], hi_max[l - 1][b]), std::max(hi_max[l - 1][c], hi_max[l - 1][e]));
+                }
+        }
+    }
     bool solid(int64_t x, int64_t y, int64_t z) const {
         const size_t at = (size_t)(x + dim * y);
         return z >= lo_min[0][at] && z <= hi_max[0][at];
@@ -336,6 +360,20 @@ int vrc_scene_shell_terrain_ex(uint32_t depth, uint64_t seed, int32_t thickness,
     return *descriptors ? VRC_OK : VRC_ERR_OUT_OF_MEMORY;
 }
 
+int vrc_octree_from_columns(uint32_t depth, const uint16_t *hi, const uint16_t *lo, uint32_t layout, uint64_t **descriptors,
+                            uint64_t *n_descriptors, uint64_t *root_index) {
+    if (depth < 3 || depth > 13 || !hi || !descriptors || !n_descriptors || !root_index) return VRC_ERR_INVALID_ARGUMENT;
+    const size_t n = (size_t)1 << (2 * depth);
+    for (size_t i = 0; i < n; i++)
+        if (hi[i] >= (1u << depth) || (lo && lo[i] > hi[i])) return VRC_ERR_INVALID_ARGUMENT;
+    ShellSource src;
+    src.init_columns(depth, hi, lo);
+    Emitter em((layout & VRC_LAYOUT_STRICT_REFERENCE) != 0, (layout & VRC_LAYOUT_NO_PAGE_HEADERS) == 0);
+    Node root = build(em, src, 0, 0, 0, 1 << depth);
+    em.finish(root.desc, 0, descriptors, n_descriptors, root_index);
+    return *descriptors ? VRC_OK : VRC_ERR_OUT_OF_MEMORY;
+}
+
 int vrc_scene_shell_terrain(uint32_t depth, uint64_t seed, int32_t thickness, int strict_reference,
                             uint64_t **descriptors, uint64_t *n_descriptors, uint64_t *root_index,
                             int32_t *height) {
@@ -394,7 +432,8 @@ int vrc_scene_shell_terrain_attachments(uint32_t depth, uint64_t seed, uint32_t 
 }
 
 int vrc_scene_diamond_square(uint32_t dim, double corner_seed, uint8_t *height, int8_t *grid) {
-    if (!is_pow2(dim) || dim > 4096 || !height) return VRC_ERR_INVALID_ARGUMENT;
+    // (the dense grid is dim^3 bytes: 4096 at most; the height field alone goes up to 16384^2 doubles = 2 GiB of host memory)
+    if (!is_pow2(dim) || dim > (grid ? 4096u : 16384u) || !height) return VRC_ERR_INVALID_ARGUMENT;
     const int n = (int)dim, size = n + 1;                     // Map.cpp:157 DATA_SIZE (samples wrap, :266-272)
     std::vector<double> hm((size_t)n * n, 0.0);
     auto at = [&](int x, int y) -> double & { return hm[(size_t)(x & (n - 1)) + (size_t)(y & (n - 1)) * n]; };

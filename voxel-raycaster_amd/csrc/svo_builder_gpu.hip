@@ -1,4 +1,5 @@
-// svo_builder_gpu.hip -- builds the SVO of the procedural scene directly in HBM.
+// svo_builder_gpu.hip -- builds the SVO of a column scene (the procedural shell terrain, or any caller-supplied height
+// field: Map::GenerateHeightBitmap's diamond-square terrain, src/map/Map.cpp:144-262) directly in HBM.
 //
 // Replaces the limits of the reference's builder for large scenes: Octree::buffer_size = 100000 descriptors
 // (include/map/Octree.h:29) and the dense char[D^3] input of Octree::Generate (src/map/Octree.cpp:13,325-327).
@@ -333,9 +334,13 @@ double now_s() {
     } while (0)
 
 // Builds the tree on the current device.  On success *d_desc owns the array (hipFree by the caller).
-int build_shell_terrain_device(hipStream_t stream, uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor,
-                               uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
-                               int32_t *probe_lohi, uint64_t **d_desc, vrc_build_info *out, std::string &error) {
+// The scene is a field of columns, column (x,y) solid for lo <= z <= hi: either the procedural shell terrain (host_hi ==
+// nullptr: seed / thickness / octave_floor, evaluated on the device) or caller-supplied uint16[dim*dim] arrays
+// (host_lo == nullptr: solid from z = 0 up) -- the 2-D field is the only thing that crosses PCIe.
+int build_columns_device(hipStream_t stream, uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor,
+                         const uint16_t *host_hi, const uint16_t *host_lo,
+                         uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
+                         int32_t *probe_lohi, uint64_t **d_desc, vrc_build_info *out, std::string &error) {
     int rc = VRC_OK;
     vrc_build_info bi;
     memset(&bi, 0, sizeof(bi));
@@ -374,8 +379,14 @@ int build_shell_terrain_device(hipStream_t stream, uint32_t depth, uint64_t seed
         temp_bytes = 2 * entries * sizeof(uint16_t);
         for (uint32_t l = 0; l <= depth; l++) { pyr.hi[l] = d_hi + off[l]; pyr.lo[l] = d_lo + off[l]; }
         const dim3 tb(256), grid0((unsigned)((dim + 255) / 256), (unsigned)dim);
-        hipLaunchKernelGGL(height_kernel, grid0, tb, 0, stream, d_hi, (int)depth, seed, (int)octave_floor);
-        hipLaunchKernelGGL(floor_kernel, grid0, tb, 0, stream, (const uint16_t *)d_hi, d_lo, (int)depth, (int)thickness);
+        if (host_hi) {
+            GB_TRY(hipMemcpyAsync(d_hi, host_hi, (size_t)(dim * dim) * sizeof(uint16_t), hipMemcpyHostToDevice, stream));
+            if (host_lo) GB_TRY(hipMemcpyAsync(d_lo, host_lo, (size_t)(dim * dim) * sizeof(uint16_t), hipMemcpyHostToDevice, stream));
+            else GB_TRY(hipMemsetAsync(d_lo, 0, (size_t)(dim * dim) * sizeof(uint16_t), stream));
+        } else {
+            hipLaunchKernelGGL(height_kernel, grid0, tb, 0, stream, d_hi, (int)depth, seed, (int)octave_floor);
+            hipLaunchKernelGGL(floor_kernel, grid0, tb, 0, stream, (const uint16_t *)d_hi, d_lo, (int)depth, (int)thickness);
+        }
         for (uint32_t l = 1; l <= depth; l++) {
             const int64_t d = dim >> l;
             hipLaunchKernelGGL(mip_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)d), tb, 0, stream, pyr.hi[l - 1], pyr.lo[l - 1],
@@ -483,6 +494,13 @@ cleanup:
     (void)hipFree(d_kv); (void)hipFree(d_mis); (void)hipFree(d_pxy); (void)hipFree(d_plohi);
     if (desc) (void)hipFree(desc);
     return rc;
+}
+
+int build_shell_terrain_device(hipStream_t stream, uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor,
+                               uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
+                               int32_t *probe_lohi, uint64_t **d_desc, vrc_build_info *out, std::string &error) {
+    return build_columns_device(stream, depth, seed, thickness, octave_floor, nullptr, nullptr, flags, validate_samples, probe_xy,
+                                n_probe, probe_lohi, d_desc, out, error);
 }
 
 }  // namespace vrc

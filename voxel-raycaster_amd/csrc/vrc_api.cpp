@@ -33,6 +33,10 @@ hipError_t launch_pack_rgba8(const float *image, uint8_t *out, size_t n_pixels, 
 int build_shell_terrain_device(hipStream_t stream, uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor,
                                uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
                                int32_t *probe_lohi, uint64_t **d_desc, vrc_build_info *out, std::string &error);
+int build_columns_device(hipStream_t stream, uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor,
+                         const uint16_t *host_hi, const uint16_t *host_lo,
+                         uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
+                         int32_t *probe_lohi, uint64_t **d_desc, vrc_build_info *out, std::string &error);
 }  // namespace vrc
 
 struct vrc_setting { std::string name, define; int64_t value; };
@@ -634,6 +638,33 @@ int vrc_build_shell_terrain(vrc_caster *h, uint32_t depth, uint64_t seed, int32_
                                                    n_probe, probe_lohi, &d, &bi, err);
     if (info) *info = bi;
     if (rc != VRC_OK) return fail(h, rc, "build_shell_terrain: %s", err.c_str());
+    if (count_only) return VRC_OK;
+    h->d_desc = d; h->n_desc = bi.n_descriptors; h->have_octree = true;
+    const int rs = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)bi.root_index);
+    if (rs != VRC_OK) return rs;
+    return fan_out_tree(h);
+}
+
+int vrc_build_heightfield(vrc_caster *h, uint32_t depth, const uint16_t *hi, const uint16_t *lo, uint32_t flags,
+                          uint64_t validate_samples, vrc_build_info *info) {
+    if (!h || depth < 3 || depth > 16 || !hi)
+        return fail(h, VRC_ERR_INVALID_ARGUMENT, "build_heightfield: need 3 <= depth <= 16 and a height field");
+    const size_t n = (size_t)1 << (2 * depth);
+    for (size_t i = 0; i < n; i++)
+        if (hi[i] >= (1u << depth) || (lo && lo[i] > hi[i]))
+            return fail(h, VRC_ERR_INVALID_ARGUMENT, "build_heightfield: column %zu needs lo <= hi < dim", i);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool count_only = (flags & VRC_BUILD_COUNT_ONLY) != 0;
+    if (!count_only) {
+        for (vrc_caster *q : h->peers) release_tree(q);
+        release_tree(h);
+    }
+    uint64_t *d = nullptr;
+    vrc_build_info bi;
+    std::string err;
+    const int rc = vrc::build_columns_device(h->stream, depth, 0, 0, 0, hi, lo, flags, validate_samples, nullptr, 0, nullptr, &d, &bi, err);
+    if (info) *info = bi;
+    if (rc != VRC_OK) return fail(h, rc, "build_heightfield: %s", err.c_str());
     if (count_only) return VRC_OK;
     h->d_desc = d; h->n_desc = bi.n_descriptors; h->have_octree = true;
     const int rs = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)bi.root_index);
