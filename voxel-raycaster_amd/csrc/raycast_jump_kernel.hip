@@ -45,6 +45,10 @@ enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4 };
 // blocks, 3 % in the hit block): the descent load issued before the jump block and used after it (+4 %: the latency is
 // already covered by the other 7 waves of the SIMD); load instructions batched by a vote of the wave until 8 / 16 / 32
 // lanes wait (+17 / +23 / +40 %: an idle lane costs more than a thin load).
+// Round 3: the one value the compiler spills inside the round loop is the thread's stack slot (every jump / descent
+// block starts with a 4-byte scratch reload of it: 6 per round); recomputed instead from the wave's number (a scalar
+// register) and v_mbcnt, the hot blocks are free of scratch accesses -- and the frame 1.7 % slower (0.707 vs 0.695 ms):
+// with 8 waves per SIMD the reload's latency is covered, the two extra VALU instructions are not.
 #ifndef VRC_ROUND_PROGRAM
 #define VRC_ROUND_PROGRAM VRC_J(true) VRC_D(true) VRC_D(true) VRC_J(true) VRC_D(true) VRC_D(true)
 #endif
