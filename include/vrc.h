@@ -14,9 +14,14 @@
  *     CLCaster.cpp:893-896); camera, lights and light_count are RETAINED
  *     pointers re-read on every vrc_compute (reference: CL_MEM_USE_HOST_PTR,
  *     CLCaster.cpp:137-139,322) -- the caller keeps them alive.
- *   - a handle drives ONE GPU and is not thread-safe (the reference is
- *     single-threaded).  Multi-GPU = one handle per GPU, each
- *     rendering its own row tiles (vrc_set_row_tiling); no collective.
+ *   - a handle is not thread-safe (the reference is single-threaded, SURVEY
+ *     8b).  A handle from vrc_create drives ONE GPU; multi-GPU is either one
+ *     such handle per GPU and process, each rendering its own row slice
+ *     (vrc_set_row_slice), or ONE group handle from vrc_create_group that
+ *     drives n GPUs from one host thread -- the reference's single synchronous
+ *     compute() (CLCaster.cpp:224-228,946-987) spread over the row bands of n
+ *     devices.  No collective either way: the SVO is replicated, tiles are
+ *     copied out by the GPU that rendered them.
  *   - the GL-shared output texture of the reference (CLCaster.cpp:278-296) is
  *     replaced by an offline float4 pixel buffer in HBM, read back with
  *     vrc_read_image_*.

@@ -13,9 +13,12 @@ raycaster is made of and store what they return:
                           of nearly opposite light / view directions amplifies the library's 1-2 ulp) -- the same
                           with the reference's fast-math flags and without them (_strict code object).
 
-The raycaster kernel itself cannot be observed on this GPU (image2d_t I/O, no image hardware on CDNA4:
-profiles/r01_reference_kernel_on_gfx950.txt), so the step loop and the UV/texel code stay a restatement.
-Nothing here reads /root/reference at run time: only the prebuilt code object travels to the GPU box."""
+The raycaster kernel's only output is write_imagef and its only atlas access read_imagef; CDNA4 has no image hardware and
+both lower to nothing (profiles/r01_reference_kernel_on_gfx950.txt).  oracle/ref_raycaster_probe.cl therefore redirects
+exactly those two builtins to buffers and runs the WHOLE kernel, unmodified otherwise, on the MI355X: the tests in the
+second half of this file compare every decision of its primary ray (written, hit voxel, face, material, texel, step
+counts, bounce count) with the oracle exactly, and what follows the library normalize statistically.
+Nothing here reads /root/reference at run time: only the prebuilt code objects travel to the GPU box."""
 import ctypes as C
 import os
 
