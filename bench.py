@@ -364,12 +364,15 @@ def main():
                 valu = pmc.get("valu_insts_per_launch")
                 if valu:
                     # the float recurrence of ray_caster_kernel.cl:558-559 (min, three masks, three fused updates = 10 wave64
-                    # instructions per 64 lane steps) is the floor of any bit-exact stepping kernel
+                    # instructions per 64 lane steps) is what any kernel that steps voxel by voxel must issue at least; the
+                    # closed-form jumps (exact_jump.hpp) are how this one gets below 12 per step on average
                     floor = ctr["steps"] / 64.0 * 10.0
                     rate = valu / avg_kernel_s / 1e9
-                    issue = {"valu_insts_per_launch": int(valu), "floor_insts": int(floor), "valu_floor_frac": round(floor / valu, 4),
+                    issue = {"valu_insts_per_launch": int(valu), "per_voxel_stepping_floor_insts": int(floor),
+                             "valu_over_stepping_floor": round(valu / floor, 4),
                              "achieved_ginst_s": round(rate, 1), "peak_ginst_s": VALU_PEAK_GINST_S,
-                             "frac": round(rate / VALU_PEAK_GINST_S, 4)}
+                             "frac": round(rate / VALU_PEAK_GINST_S, 4),
+                             "note": "instruction count, not issue time: fp64 / reciprocal / 32-bit multiply instructions of the jump block take 2-4 issue slots"}
             else:
                 pmc_note = "profiles/traffic_latest.json was measured on other kernel sources: re-run tools/gpu_profile.sh + tools/update_profiles.py"
         out = {
@@ -392,8 +395,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel": "raycast_svo_kernel",
                          "binding_roof": "valu_issue",
-                         "note": "exact-parity stepping is VALU-issue bound (DESIGN.md 4): frac is kept on HBM as BASELINE defines it, "
-                                 "valu_issue.frac says how close the kernel is to the roof that binds it",
+                         "note": "exact-parity traversal is bound by VALU issue and by the latency of its dependent chains (DESIGN.md 4), not by "
+                                 "HBM: frac is kept on HBM as BASELINE defines it, valu_issue says what the kernel issues",
                          "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"], "valu_issue": issue,
                          "pmc_source": pmc_note, "kernel_source_hash": kernel_source_hash()},
         }

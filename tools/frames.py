@@ -22,7 +22,7 @@ c = bench.make_caster(sc, a.width, a.height, 0, light_count=a.lights, hit_record
 assert c.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", a.mode)
 for kv in a.set:
     k, v = kv.split("=")
-    assert c.add_to_settings_buffer(k, k.upper(), int(v))
+    assert c.overwrite_setting(k, int(v)) or c.add_to_settings_buffer(k, k.upper(), int(v))
 for _ in range(2):
     assert c.compute(), c.last_error()
 c.timing_reset()
@@ -37,7 +37,7 @@ if a.streams > 1:
         assert q.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", a.mode)
         for kv in a.set:
             k, v = kv.split("=")
-            assert q.add_to_settings_buffer(k, k.upper(), int(v))
+            assert q.overwrite_setting(k, int(v)) or q.add_to_settings_buffer(k, k.upper(), int(v))
         assert q.compute(), q.last_error()
     t0 = time.perf_counter()
     for _ in range(a.frames):

@@ -24,5 +24,14 @@ done
 cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py $OUT/pmc_mode0 raycast_svo_kernel > $OUT/pmc_mode0_summary.txt 2>&1
 python tools/pmc_summary.py $OUT/pmc_mode1 raycast_jump_kernel > $OUT/pmc_mode1_summary.txt 2>&1
+[ -x tools/ubench/valu_issue ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/valu_issue tools/ubench/valu_issue.hip > $OUT/valu_issue_build.log 2>&1
 tools/ubench/valu_issue > $OUT/valu_issue.txt 2>&1
+# the other instances: C4 (4K, 2 lights: multi-light instance), C2 (depth 10, primary only), headline without jumps
+pmc2() { name=$1; shift; mkdir -p $OUT/pmc_$name; cd /tmp; for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+    tag=$(echo $set | cut -d' ' -f1); timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$name/$tag -o $tag -- python3 $GRAFT_REPO_ROOT/tools/frames.py --frames 3 --hit-records 0 "$@" > $OUT/pmc_$name/$tag.log 2>&1; done
+  cd $GRAFT_REPO_ROOT; python tools/pmc_summary.py $OUT/pmc_$name raycast_svo_kernel > $OUT/pmc_${name}_summary.txt 2>&1; tail -1 $OUT/pmc_$name/FETCH_SIZE.log | cut -c1-160 >> $OUT/pmc_${name}_summary.txt; }
+pmc2 c4_4k_2lights --width 3840 --height 2160 --lights 2
+pmc2 c2_d10_primary --depth 10 --set shadow_rays=0
+pmc2 headline_no_jumps --set jump_min_run=16777216
+pmc2 headline_4lights --lights 4
 echo done
