@@ -52,9 +52,8 @@ static bool jumped(State s, int left, int mix, const std::vector<Snap> &trace, O
         if (mix == 0 || (rng() % (unsigned)mix) != 0) {
             uint32_t fills = 0;
             if (sloppy != 0) jump_rows_build(true, true, rows, s.t[0], s.t[1], s.t[2], s.d[0], s.d[1], s.d[2], tab, 1, fills);
-            else memset(tab, 0, sizeof(tab));      // "no entry" everywhere
-            g_fills += fills;
-            JumpOut r = stretch_jump(s.t[0], s.t[1], s.t[2], s.d[0], s.d[1], s.d[2], s.n[0], s.n[1], s.n[2], left - it, tab, 1);
+            g_fills += fills;                      // (sloppy == 0: no row is ever built, every pair is solved on the spot)
+            JumpOut r = stretch_jump(s.t[0], s.t[1], s.t[2], s.d[0], s.d[1], s.d[2], s.n[0], s.n[1], s.n[2], left - it, tab, 1, rows);
             if (r.iterations < 1) return false;
             g_jumps++; g_jump_iters += r.iterations;
             it += r.iterations;

@@ -133,7 +133,9 @@ VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // per-ray table of the Euclid runs (jump_rows_build): one dword per (binade row, axis pair),
-//   row = e - kJumpFirstBinade (0 <= row < kJumpBinades), pairs xy, xz, yz:   tab[(3 * row + pair) * stride]
+//   row = e - kJumpFirstBinade (0 <= row < kJumpBinades), pairs xy, xz, yz:   tab[(3 * (row % kJumpRing) + pair) * stride]
+// A ray's intersection_t only grow, so it needs the row of the binade it is in and those ahead: the table is a ring of
+// kJumpRing rows, and `rows` (a bit per row, kept by the caller) says which rows it holds right now.
 //   bits 0-23  s: s * inc_a == g (mod inc_b), 0 <= s < inc_b        bits 24-31  g = gcd(inc_a, inc_b)
 //   g == 255: the gcd is 255 or more (the pair is solved afresh when it is needed: rare);  whole dword 0: no entry
 // The increments depend on (delta_t, binade) only.  In HBM (RaycastParams::jump_cache), one table per lane, interleaved
@@ -144,7 +146,10 @@ VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
 #endif
 constexpr int kJumpFirstBinade = 127 + VRC_JUMP_FIRST_LOG2;   // no table below t = 128: a binade of fewer voxels than a Euclid run costs
 constexpr int kJumpBinades = 12;              // t < 2^19
-constexpr int kJumpTableDwords = 3 * kJumpBinades;
+constexpr int kJumpRing = 4;                  // (the slot mask in jump_rows_build is written for 4)
+static_assert(kJumpRing == 4, "jump_rows_build: slot mask");
+constexpr int kJumpRingUnused = 0;                  // rows kept per ray: a ring indexed by row % kJumpRing (intersection_t only grows)
+constexpr int kJumpTableDwords = 3 * kJumpRing;
 
 // s and g with s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib; 1 <= ia, ib < 2^24 -- for the three axis pairs at
 // once (three independent chains per loop trip).  Extended Euclid on exact integers held in floats.  The quotient
@@ -199,9 +204,10 @@ VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float
     }
     if (active) {
         int32_t s, g;
-        euclid_finish(cxy, iy, s, g); tab[(3 * row + 0) * stride] = vxy ? jump_entry_pack(s, g) : 0u;
-        euclid_finish(cxz, iz, s, g); tab[(3 * row + 1) * stride] = vxz ? jump_entry_pack(s, g) : 0u;
-        euclid_finish(cyz, iz, s, g); tab[(3 * row + 2) * stride] = vyz ? jump_entry_pack(s, g) : 0u;
+        const int slot = row % kJumpRing;
+        euclid_finish(cxy, iy, s, g); tab[(3 * slot + 0) * stride] = vxy ? jump_entry_pack(s, g) : 0u;
+        euclid_finish(cxz, iz, s, g); tab[(3 * slot + 1) * stride] = vxz ? jump_entry_pack(s, g) : 0u;
+        euclid_finish(cyz, iz, s, g); tab[(3 * slot + 2) * stride] = vyz ? jump_entry_pack(s, g) : 0u;
         solves += (vxy ? 1u : 0u) + (vxz ? 1u : 0u) + (vyz ? 1u : 0u);
     }
 }
@@ -222,22 +228,30 @@ VRC_HD uint32_t jump_rows_needed(float tx, float ty, float tz) {
 VRC_HD void jump_rows_build(bool want, bool live, uint32_t &rows, float tx, float ty, float tz, float dx, float dy, float dz,
                             uint32_t *tab, int stride, uint32_t &solves) {
     uint32_t need = want ? (jump_rows_needed(tx, ty, tz) & ~rows) : 0u;
+    // the lowest row this ray can still ask for: the binade of its smallest intersection_t (negative / tiny t: row 0)
+    const float tmin = tx < ty ? (tx < tz ? tx : tz) : (ty < tz ? ty : tz);
+    const int32_t lo_e = (int32_t)(f2u(tmin) >> 23);
+    const int lo_row = (lo_e >= kJumpFirstBinade && lo_e < 256) ? lo_e - kJumpFirstBinade : 0;
     unsigned long long m;
     while ((m = VRC_BALLOT(need != 0u)) != 0ULL) {
         const uint32_t first = VRC_FIRST_LANE_VALUE(need, m);
         const int row = __builtin_ctz(first);
-        const bool build = live && !((rows >> row) & 1u);
+        // a lane that asked for the row gets it whatever it evicts (the loop must end; a pair whose row was evicted is
+        // solved on the spot by stretch_jump); a lane that merely rides along takes it only if the row lies in the window of
+        // kJumpRing rows from the binade it is in -- further ahead it would evict a row the ray still uses
+        const bool build = live && !((rows >> row) & 1u) && (((need >> row) & 1u) || (row >= lo_row && row - lo_row < kJumpRing));
         jump_table_build_row(build, row, dx, dy, dz, tab, stride, solves);
-        rows |= build ? (1u << row) : 0u;
+        if (build) rows = (rows & ~(0x11111111u << (row % kJumpRing))) | (1u << row);   // the rows that shared its ring slot are gone
         need &= ~rows;
     }
 }
-VRC_HD uint32_t jump_table_entry(const uint32_t *tab, int stride, int pair, int32_t e) {
+VRC_HD uint32_t jump_table_entry(const uint32_t *tab, int stride, uint32_t rows, int pair, int32_t e) {
     const uint32_t row = (uint32_t)(e - kJumpFirstBinade);
+    const bool have = row < (uint32_t)kJumpBinades && ((rows >> (row & 31u)) & 1u);
 #ifdef VRC_JUMP_FAKE_TABLE   // (timing experiment only: no load, wrong tie counts)
-    return row < (uint32_t)kJumpBinades ? ((1u << 24) | (12345u + (uint32_t)pair)) : 0u;
+    return have ? ((1u << 24) | (12345u + (uint32_t)pair)) : 0u;
 #endif
-    return row < (uint32_t)kJumpBinades ? tab[(3 * (int)row + pair) * stride] : 0u;
+    return have ? tab[(3 * (int)(row % (uint32_t)kJumpRing) + pair) * stride] : 0u;   // a row the table does not hold: "no entry"
 }
 
 // One regular axis pair in a common binade: the consumed events are Ma + i*ia (0 <= i < ma) and Mb + j*ib (0 <= j < mb),
@@ -358,14 +372,14 @@ struct JumpOut {
 };
 
 // One exact multi-iteration jump.  t*, n* (countdowns >= 1) are updated in place.  `left` = iterations the loop may
-// still run (max_distance - distance_traveled, >= 1).  `tab`, `stride`: the ray's table (jump_table_build).
+// still run (max_distance - distance_traveled, >= 1).  `tab`, `stride`, `rows`: the ray's table (jump_rows_build).
 VRC_HD JumpOut stretch_jump(float &tx, float &ty, float &tz, float dx, float dy, float dz, int32_t &nx, int32_t &ny,
-                            int32_t &nz, int32_t left, const uint32_t *tab, int stride) {
+                            int32_t &nz, int32_t left, const uint32_t *tab, int stride, uint32_t rows) {
     // the table dwords first: their addresses need the exponents only, and the loads have the whole decode to arrive
     const int32_t ex0 = (int32_t)(f2u(tx) >> 23), ey0 = (int32_t)(f2u(ty) >> 23), ez0 = (int32_t)(f2u(tz) >> 23);
-    const uint32_t txy = (ex0 == ey0) ? jump_table_entry(tab, stride, 0, ex0) : 0u;
-    const uint32_t txz = (ex0 == ez0) ? jump_table_entry(tab, stride, 1, ex0) : 0u;
-    const uint32_t tyz = (ey0 == ez0) ? jump_table_entry(tab, stride, 2, ey0) : 0u;
+    const uint32_t txy = (ex0 == ey0) ? jump_table_entry(tab, stride, rows, 0, ex0) : 0u;
+    const uint32_t txz = (ex0 == ez0) ? jump_table_entry(tab, stride, rows, 1, ex0) : 0u;
+    const uint32_t tyz = (ey0 == ez0) ? jump_table_entry(tab, stride, rows, 2, ey0) : 0u;
     JumpAxis ax = jump_axis(tx, dx, nx), ay = jump_axis(ty, dy, ny), az = jump_axis(tz, dz, nz);
     float X = ax.E < ay.E ? ax.E : ay.E;
     X = X < az.E ? X : az.E;

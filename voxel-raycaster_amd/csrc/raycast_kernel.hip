@@ -150,8 +150,16 @@ template <bool kJump, bool kMulti, bool kTuned>
 __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
     __shared__ unsigned long long block_ctr[kCtrCount];
+    __shared__ int s_jump_slot;
     const int tid = threadIdx.x;
     if (tid < kCtrCount) block_ctr[tid] = 0;
+    if (kJump && tid == 0) {
+        // the block's slot in the table buffer: tables exist for RESIDENT blocks only (they stay in the L2 / MALL), so a
+        // block takes a free slot when it starts -- there are more slots than blocks the chip can hold -- and gives it back
+        unsigned i = (unsigned)(((unsigned long long)blockIdx.x * 2654435761ULL) % (unsigned)p.jump_slot_count);
+        while (atomicCAS(&p.jump_slots[i], 0u, 1u) != 0u) i = (i + 1u == (unsigned)p.jump_slot_count) ? 0u : i + 1u;
+        s_jump_slot = (int)i;
+    }
     __syncthreads();
 
     int px, py, brow;
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     // and the bit mask of the rows built for the ray's current direction
     uint32_t *jtab = nullptr;
     uint32_t jrows = 0;
-    if (kJump) jtab = p.jump_cache + ((size_t)blockIdx.x * kTilesPerBlock + (tid >> 6)) * (size_t)(kJumpTableDwords * 64) + (tid & 63);
+    if (kJump) jtab = p.jump_cache + ((size_t)s_jump_slot * kTilesPerBlock + (tid >> 6)) * (size_t)(kJumpTableDwords * 64) + (tid & 63);
 
     if (in_image) {
         if (!ray_setup(r, p, pix)) {
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                     asm volatile("; VRC_MARK jump_block_begin");
                     int inx = (int)nx, iny = (int)ny, inz = (int)nz;
                     const JumpOut jo = stretch_jump(r.itx, r.ity, r.itz, r.dtx, r.dty, r.dtz, inx, iny, inz,
-                                                    r.max_distance - r.distance_traveled, jtab, 64);
+                                                    r.max_distance - r.distance_traveled, jtab, 64, jrows);
 #ifdef VRC_SCHED_STATS
                     atomicAdd(&g_jump_stats[1], 1ULL);
                     atomicAdd(&g_jump_stats[2], (unsigned long long)jo.iterations);
@@ -675,7 +683,8 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     }
 #endif
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
-    publish_counters(p, block_ctr, vals);
+    publish_counters(p, block_ctr, vals);                 // (a __syncthreads inside: every wave of the block is through with its tables)
+    if (kJump && tid == 0) atomicExch(&p.jump_slots[s_jump_slot], 0u);
 }
 
 __global__ void reduce_counters_kernel(const unsigned long long *partials, int nblocks, unsigned long long *out) {
@@ -804,7 +813,7 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
                            p.widen_nodes != 0 && p.arith_mask != 0 && p.safe_run != 0 && p.single_step != 0 &&
                            p.shade_threshold == kDefaultShadeThreshold && p.safe_steps == kDefaultSafeSteps &&
                            p.exact_steps == kDefaultExactSteps && p.burst_steps == kDefaultBurstSteps;
-        if (jump && !p.jump_cache) return hipErrorInvalidValue;
+        if (jump && (!p.jump_cache || !p.jump_slots || p.jump_slot_count < 1)) return hipErrorInvalidValue;
 #define VRC_LAUNCH(J, M, T) hipLaunchKernelGGL((raycast_svo_kernel<J, M, T>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p)
         if (jump) {
             if (multi && tuned) VRC_LAUNCH(true, true, true);

@@ -56,7 +56,7 @@ struct vrc_caster {
     bool last_frame_wrote_hits = false;   // d_hits belongs to the last enqueued frame (setting hit_records was on)
     uint32_t *d_attach_lookup = nullptr; uint64_t *d_attach = nullptr; uint64_t n_attach = 0;
     float *d_viewport = nullptr; float *d_image = nullptr; int32_t *d_hits = nullptr; uint8_t *d_rgba8 = nullptr;
-    uint32_t *d_jump_cache = nullptr; size_t jump_cache_bytes = 0;   // per-ray Euclid tables of the exact closed-form jumps (exact_jump.hpp)
+    uint32_t *d_jump_cache = nullptr, *d_jump_slots = nullptr; int jump_slot_count = 0;   // Euclid tables of the exact closed-form jumps (exact_jump.hpp), per resident block
     int32_t width = 0, height = 0;
     bool sliced = false;                  // viewport / image / hits hold only this rank's rows
     int32_t buffer_rows = 0;              // rows the three buffers hold
@@ -205,7 +205,7 @@ void reference_table_row(int32_t width, int32_t height, int32_t row, float *out)
 // table == nullptr: the reference's own table
 int install_viewport(vrc_caster *h, int32_t width, int32_t height, const float *table) {
     HIP_TRY(h, hipSetDevice(h->device));
-    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_jump_cache);
+    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_jump_cache); release(h->d_jump_slots); h->jump_slot_count = 0;
     h->width = width; h->height = height;
     h->buffer_rows = h->sliced ? local_row_count(h) : height;
     h->validated = false;
@@ -236,14 +236,18 @@ int install_viewport(vrc_caster *h, int32_t width, int32_t height, const float *
     return VRC_OK;
 }
 
-// the per-ray Euclid tables of the exact closed-form jumps (exact_jump.hpp): kJumpTableDwordsPerLane dwords per lane of every block
+// the per-ray Euclid tables of the exact closed-form jumps (exact_jump.hpp): kJumpTableDwordsPerLane dwords per lane of a
+// block SLOT.  Only resident blocks hold a slot (the kernel takes and returns them), so the buffer is sized for the chip,
+// not for the frame: at most kJumpSlots slots of 12 KB.
 int ensure_jump_cache(vrc_caster *h, int nblocks) {
-    const size_t bytes = (size_t)nblocks * vrc::kBlockThreads * vrc::kJumpTableDwordsPerLane * sizeof(uint32_t);
-    if (h->d_jump_cache && h->jump_cache_bytes >= bytes) return VRC_OK;
-    release(h->d_jump_cache);
-    h->jump_cache_bytes = 0;
-    HIP_TRY(h, hipMalloc((void **)&h->d_jump_cache, bytes));      // every ray writes its whole table before it reads it
-    h->jump_cache_bytes = bytes;
+    const int slots = std::max(1, std::min(nblocks, vrc::kJumpSlots));
+    if (h->d_jump_cache && h->jump_slot_count >= slots) return VRC_OK;
+    release(h->d_jump_cache); release(h->d_jump_slots); h->jump_slot_count = 0; release(h->d_jump_slots);
+    h->jump_slot_count = 0;
+    HIP_TRY(h, hipMalloc((void **)&h->d_jump_cache, (size_t)slots * vrc::kBlockThreads * vrc::kJumpTableDwordsPerLane * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_jump_slots, (size_t)slots * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemsetAsync(h->d_jump_slots, 0, (size_t)slots * sizeof(uint32_t), h->stream));
+    h->jump_slot_count = slots;
     return VRC_OK;
 }
 
@@ -403,7 +407,7 @@ int vrc_destroy(vrc_caster *h) {
     for (auto &p : h->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     release_tree(h);
     release(h->d_map);
-    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_jump_cache); release(h->d_atlas);
+    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_jump_cache); release(h->d_jump_slots); h->jump_slot_count = 0; release(h->d_atlas);
     release(h->d_partials); release(h->d_counters); release(h->d_frame);
     if (h->wd_flag) (void)hipHostFree(h->wd_flag);
     if (h->pinned_stage) (void)hipHostFree(h->pinned_stage);
@@ -717,7 +721,7 @@ int vrc_create_viewport_table(vrc_caster *h, int32_t width, int32_t height, cons
 int vrc_release_viewport(vrc_caster *h) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     if (!h->d_viewport) return fail(h, VRC_ERR_NOT_FOUND, "release_viewport: no viewport");
-    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_jump_cache);
+    release(h->d_viewport); release(h->d_image); release(h->d_hits); release(h->d_rgba8); release(h->d_jump_cache); release(h->d_jump_slots); h->jump_slot_count = 0;
     h->width = h->height = h->buffer_rows = 0; h->validated = false;
     FOR_PEERS(h, vrc_release_viewport(q));
     return VRC_OK;
@@ -943,7 +947,7 @@ int compute_async_one(vrc_caster *h) {
     if (svo && p.stepping_mode == 0 && p.jump_min_run < vrc::kJumpOff) {
         const int rc = ensure_jump_cache(h, nblocks);
         if (rc != VRC_OK) return rc;
-        p.jump_cache = h->d_jump_cache;
+        p.jump_cache = h->d_jump_cache; p.jump_slots = h->d_jump_slots; p.jump_slot_count = h->jump_slot_count;
     }
     h->last_blocks = nblocks;
     h->frames_enqueued++;

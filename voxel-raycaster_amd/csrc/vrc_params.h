@@ -25,7 +25,8 @@ constexpr int kDefaultBurstSteps = 48, kDefaultShadeThreshold = 64, kDefaultSafe
 // depth from which they are on by default (measured: depth 10 loses 15 %, depth 12 gains 15 %, depth 16 is 3.3x faster)
 constexpr int kDefaultJumpMinRun = 96, kDefaultJumpMinDepth = 12;
 constexpr int kJumpOff = 1 << 24;      // jump_min_run >= this: the instances without the jump block
-constexpr int kJumpTableDwordsPerLane = 36;   // == kJumpTableDwords of exact_jump.hpp (checked in raycast_kernel.hip)
+constexpr int kJumpTableDwordsPerLane = 12;   // == kJumpTableDwords of exact_jump.hpp (checked in raycast_kernel.hip)
+constexpr int kJumpSlots = 4096;              // table slots for resident blocks (>= 256 CUs x 6 blocks; a block takes one while it runs)
 constexpr int kMaxLights = 8;         // light slots (include/LightController.h:95)
 constexpr int kMaxLevels = 24;        // descriptor levels the LDS stack can hold (dim <= 2^24)
 
@@ -81,7 +82,9 @@ struct RaycastParams {
     int32_t shade_threshold;          // ... and before the hit block runs
     int32_t widen_nodes;              // widen an empty node over empty siblings ahead of the ray (results unchanged)
     int32_t jump_min_run;             // exact closed-form jumps for stretches of at least this many (estimated) iterations (1<<24 = off)
-    uint32_t *jump_cache;             // kJumpTableDwords dwords per lane of every block: the per-ray Euclid tables of exact_jump.hpp
+    uint32_t *jump_cache;             // the per-ray Euclid tables of exact_jump.hpp: kJumpTableDwordsPerLane dwords per lane of a block slot
+    uint32_t *jump_slots;             // one flag per block slot (0 free / 1 taken): a block takes a slot when it starts
+    int32_t jump_slot_count;
     int32_t lds_pad_bytes;            // experiment knob: extra dynamic LDS to lower occupancy
     int32_t xcd_mode;                 // block->tile map: 0 contiguous eighth per XCD, 1 tile rows interleaved over XCDs, 2 none
     // row tiling (multi-GPU)
