@@ -3,6 +3,7 @@
 // must land exactly on a recorded state after every single jump (intersection_t bits, countdowns, iteration count) and
 // agree on the face mask of the leaving iteration and on the exit / cap verdict.
 // g++ -O2 -ffp-contract=off -std=c++17 -o jump_vs_loop jump_vs_loop.cpp ; ./jump_vs_loop [cases] [seed]
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -78,10 +79,33 @@ static bool jumped(State s, int left, int mix, const std::vector<Snap> &trace, O
     return true;
 }
 
+// pair_solve against the definition: s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib
+static long check_pair_solve(std::mt19937_64 &rng, long n) {
+    long bad = 0;
+    for (long c = 0; c < n; c++) {
+        int bits_a = 1 + (int)(rng() % 24), bits_b = 1 + (int)(rng() % 24);
+        int32_t ia = 1 + (int32_t)(rng() % ((1u << bits_a) - 0u)) % ((1 << 24) - 1), ib = 1 + (int32_t)(rng() % ((1u << bits_b) - 0u)) % ((1 << 24) - 1);
+        const int kind = (int)(rng() % 8);
+        if (kind == 0) ia = ib;
+        if (kind == 1) ia = (int32_t)std::min<int64_t>((int64_t)ib * (1 + (int64_t)(rng() % 5)), (1 << 24) - 1);
+        if (kind == 2) ib = 1;
+        if (kind == 3) { int32_t g = 1 + (int32_t)(rng() % 4000); ia = std::max(1, ia / g) * g; ib = std::max(1, ib / g) * g; if (ia >= (1 << 24)) ia = g; if (ib >= (1 << 24)) ib = g; }
+        if (kind == 4) { ia = (1 << 24) - 1 - (int32_t)(rng() % 3); ib = (1 << 24) - 1 - (int32_t)(rng() % 1000); }
+        int32_t s = -1, g = -1;
+        pair_solve(true, ia, ib, s, g);
+        int64_t a = ia, b = ib;
+        while (b) { int64_t t = a % b; a = b; b = t; }
+        const bool ok = g == (int32_t)a && s >= 0 && s < ib && (int64_t)(((__int128)s * ia - g) % ib) == 0;
+        if (!ok) { if (bad < 10) printf("pair_solve(%d, %d) -> s=%d g=%d (gcd %ld)\n", ia, ib, s, g, (long)a); bad++; }
+    }
+    return bad;
+}
+
 int main(int argc, char **argv) {
     long cases = argc > 1 ? atol(argv[1]) : 200000;
     unsigned seed = argc > 2 ? (unsigned)atoi(argv[2]) : 1;
     std::mt19937_64 rng(seed);
+    if (check_pair_solve(rng, 5 * cases)) { printf("pair_solve mismatches\n"); return 1; }
     std::uniform_real_distribution<double> U(0.0, 1.0);
     long bad = 0;
     std::vector<Snap> trace;

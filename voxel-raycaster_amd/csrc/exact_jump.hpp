@@ -151,39 +151,45 @@ static_assert(kJumpRing == 4, "jump_rows_build: slot mask");
 constexpr int kJumpRingUnused = 0;                  // rows kept per ray: a ring indexed by row % kJumpRing (intersection_t only grows)
 constexpr int kJumpTableDwords = 3 * kJumpRing;
 
-// s and g with s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib; 1 <= ia, ib < 2^24 -- for the three axis pairs at
-// once (three independent chains per loop trip).  Extended Euclid on exact integers held in floats.  The quotient
-// estimate is rounded DOWN (never above the true floor): a short quotient only splits one Euclid step into two, so
-// remainders stay non-negative, the cofactors alternate in sign and stay below ib, and every fma is exact.
-// Branch-free body; the loop runs while any chain of any lane of the wave has a remainder left.
+// s and g with s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib; 1 <= ia, ib < 2^24.  Extended Euclid on exact integers
+// held in floats, two steps per trip with the roles of the two remainders alternating (no conditional swaps):
+//     (r0, s0) -= q  * (r1, s1)     q  = floor(r0 / r1)        then        (r1, s1) -= q' * (r0, s0)     q' = floor(r1 / r0)
+// with the invariant r_i == s_i * ia (mod ib).  The quotient estimate is rounded DOWN (never above the true floor) and
+// then raised by one where the remainder allows, so remainders stay non-negative and every fma is exact; for quotients
+// below 2^20 that is the exact floor, a larger one may come out short -- the step is then only partial, the other
+// remainder's step finds a zero quotient and does nothing, and the next trip finishes it.  A zero remainder makes every
+// later step a no-op, so lanes simply idle until the last chain of the wave is through.
 struct EuclidChain { float r0, s0, r1, s1; };
 VRC_HD void euclid_init(EuclidChain &c, bool active, int32_t ia, int32_t ib) {
-    c.r0 = (float)ib; c.s0 = 0.0f; c.r1 = active ? (float)ia : 0.0f; c.s1 = 1.0f;   // invariant: r_i == s_i * ia (mod ib)
+    c.r0 = (float)ib; c.s0 = 0.0f; c.r1 = active ? (float)ia : 0.0f; c.s1 = 1.0f;
+}
+// (a, sa) -= floor(a / b) * (b, sb); nothing when b == 0
+VRC_HD void euclid_reduce(float &a, float &sa, float b, float sb) {
+    float q = __builtin_floorf(a * (fast_rcp(b) * 0.99999952f));  // <= floor(a / b), short by < 2^-20 relative (b == 0: inf or NaN)
+    q = (b == 0.0f) ? 0.0f : q;
+    float n = __builtin_fmaf(-q, b, a);                           // exact, >= 0
+    const bool up = n >= b && b != 0.0f;                          // an exact-integer ratio k floors to k - 1: one fix
+    q += up ? 1.0f : 0.0f;
+    n -= up ? b : 0.0f;
+    sa = __builtin_fmaf(-q, sb, sa);                              // exact: the cofactors stay below ib in magnitude
+    a = n;
 }
 VRC_HD void euclid_step(EuclidChain &c) {
-    const bool done = c.r1 == 0.0f;
-    float q = __builtin_floorf(c.r0 * (fast_rcp(c.r1) * 0.99999952f));   // <= floor(r0 / r1), short by < 2^-20 relative
-    q = done ? 0.0f : q;                                          // (r1 == 0: the estimate is inf; q = 0 leaves the chain as it is)
-    float n0 = __builtin_fmaf(-q, c.r1, c.r0);                    // exact, >= 0
-    const bool up = n0 >= c.r1 && !done;                          // an exact-integer ratio k floors to k - 1: one fix
-    q += up ? 1.0f : 0.0f;
-    n0 -= up ? c.r1 : 0.0f;
-    const float t0 = __builtin_fmaf(-q, c.s1, c.s0);              // exact
-    const bool swap = n0 < c.r1;                                  // a full step: the pair moves on; otherwise only r0 shrinks
-    const float nr0 = swap ? c.r1 : n0, ns0 = swap ? c.s1 : t0;
-    c.r1 = swap ? n0 : c.r1; c.s1 = swap ? t0 : c.s1;
-    c.r0 = nr0; c.s0 = ns0;
+    euclid_reduce(c.r0, c.s0, c.r1, c.s1);
+    euclid_reduce(c.r1, c.s1, c.r0, c.s0);
 }
+VRC_HD bool euclid_busy(const EuclidChain &c) { return c.r0 != 0.0f && c.r1 != 0.0f; }
 VRC_HD void euclid_finish(const EuclidChain &c, int32_t ib, int32_t &s_out, int32_t &g_out) {
-    g_out = (int32_t)c.r0;
-    int32_t s = (int32_t)c.s0;
+    const bool first = c.r1 == 0.0f;                              // the remainder that is left holds the gcd
+    g_out = (int32_t)(first ? c.r0 : c.r1);
+    int32_t s = (int32_t)(first ? c.s0 : c.s1);
     s += (s < 0) ? ib : 0;
     s_out = (s >= ib) ? 0 : s;
 }
 VRC_HD void pair_solve(bool active, int32_t ia, int32_t ib, int32_t &s_out, int32_t &g_out) {
     EuclidChain c;
     euclid_init(c, active, ia, ib);
-    while (VRC_WAVE_ANY(c.r1 != 0.0f)) euclid_step(c);
+    while (VRC_WAVE_ANY(euclid_busy(c))) euclid_step(c);
     euclid_finish(c, ib, s_out, g_out);
 }
 VRC_HD uint32_t jump_entry_pack(int32_t s, int32_t g) { return (uint32_t)s | ((uint32_t)(g < 255 ? g : 255) << 24); }
@@ -199,7 +205,7 @@ VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float
     const bool vxy = okx && oky, vxz = okx && okz, vyz = oky && okz;
     EuclidChain cxy, cxz, cyz;
     euclid_init(cxy, vxy, ix, iy); euclid_init(cxz, vxz, ix, iz); euclid_init(cyz, vyz, iy, iz);
-    while (VRC_WAVE_ANY(cxy.r1 != 0.0f || cxz.r1 != 0.0f || cyz.r1 != 0.0f)) {
+    while (VRC_WAVE_ANY(euclid_busy(cxy) || euclid_busy(cxz) || euclid_busy(cyz))) {
         euclid_step(cxy); euclid_step(cxz); euclid_step(cyz);
     }
     if (active) {
