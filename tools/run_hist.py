@@ -14,11 +14,12 @@ def hist(c, name, sets=()):
     for k, v in sets:
         assert c.add_to_settings_buffer(k, k.upper(), v)
     assert c.compute(), c.last_error()
-    buf = (C.c_ulonglong * 96)()
+    buf = (C.c_ulonglong * 104)()     # 3 x 32 histogram + 8 jump counters
     assert vrc.lib.vrc_stats_run_hist(buf, 1) == 0
     assert c.compute(), c.last_error()
     assert vrc.lib.vrc_stats_run_hist(buf, 1) == 0
-    h = np.array(buf[:], dtype=np.uint64).reshape(3, 32)
+    h = np.array(buf[:96], dtype=np.uint64).reshape(3, 32)
+    js = [int(v) for v in buf[96:104]]
     ctr = c.counters()
     tot_e, tot_s = int(h[0].sum()), int(h[1].sum())
     print(f"## {name}: {tot_e / 1e6:.1f} M node events, {tot_s / 1e9:.2f} G lane steps (counter: {ctr['steps'] / 1e9:.2f} G), "
@@ -30,7 +31,9 @@ def hist(c, name, sets=()):
             continue
         print(f"| {1 << b}..{(2 << b) - 1} | {int(h[0][b])} | {h[0][b] / tot_e:.4f} | {int(h[1][b])} | {h[1][b] / tot_s:.4f} | "
               f"{h[1][b:].sum() / tot_s:.4f} | {int(h[2][b])} | {h[2][b:].sum() / tot_s:.4f} |")
-    print(json.dumps({"scene": name, "sched": c.scheduler_stats()}), flush=True)
+    print(json.dumps({"scene": name, "sched": c.scheduler_stats(),
+                      "jumps": dict(block_passes=js[0], lane_jumps=js[1], iterations_covered=js[2], left_node=js[3], capped=js[4],
+                                    pair_solves=js[5], lanes_wanting=js[6], rounds=js[7])}), flush=True)
 
 
 def device_caster(depth, w=1920, h=1080, thickness=2):
