@@ -170,6 +170,8 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
         }
     }
 
+    // (compiled in: this kernel does not read the live `shade_threshold` setting -- every value below a full tile measured
+    // slower, see VRC_JUMP_SHADE_THRESHOLD above; the exact kernel's untuned instances do honour it)
     const int shade_threshold = VRC_JUMP_SHADE_THRESHOLD;
     int rounds_left = p.watchdog_rounds;
 #ifdef VRC_SCHED_STATS
