@@ -1,9 +1,14 @@
 """Host check of voxel-raycaster_amd/csrc/exact_jump.hpp (the closed-form multi-iteration DDA jump):
 the same header the gfx950 kernel compiles, driven on random ray states against the plain float
-loop of kernels/ray_caster_kernel.cl:558-560.  Every field must match bit for bit: the three
-intersection_t values, the countdowns, the number of loop iterations, the face mask of the last
-iteration and the exit/cap verdict.  A second build perturbs the reciprocal estimate by +-1 ulp
-like the hardware v_rcp_f32 to exercise the integer fix-ups."""
+loop of kernels/ray_caster_kernel.cl:558-560.  The plain loop records the state after every iteration;
+after EVERY jump the three intersection_t values (bits), the countdowns and the iteration count must sit
+on a recorded state, and the face mask of the leaving iteration and the exit / cap verdict must agree.
+The states cover ties (equal, rational and power-of-two direction ratios), frozen axes (negative, zero
+and tiny t, slow axes below delta_t, unsettled half-way roundings), binade ends, binades up to 2^18,
+countdowns up to 40000, step caps inside the stretch, tables kept up, cut short or absent (pairs solved on
+the spot), jumps mixed with plain steps.  pair_solve (extended Euclid in floats) is checked against its
+definition first.  A second build perturbs the reciprocal estimate by +-1 ulp like the hardware
+v_rcp_f32 to exercise the integer fix-ups."""
 import os
 import subprocess
 

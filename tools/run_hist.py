@@ -14,7 +14,7 @@ def hist(c, name, sets=()):
     for k, v in sets:
         assert c.add_to_settings_buffer(k, k.upper(), v)
     assert c.compute(), c.last_error()
-    buf = (C.c_ulonglong * 104)()     # 3 x 32 histogram + 8 jump counters
+    buf = (C.c_ulonglong * 108)()     # 3 x 32 histogram + 8 jump counters
     assert vrc.lib.vrc_stats_run_hist(buf, 1) == 0
     assert c.compute(), c.last_error()
     assert vrc.lib.vrc_stats_run_hist(buf, 1) == 0

@@ -52,6 +52,12 @@
 
 namespace vrc {
 
+#if defined(VRC_SCHED_STATS) && defined(__HIPCC__)
+// profiling build only: [0] lanes that had to solve a pair on the spot (no usable table entry), [1] lanes that sat through
+// such a solve for another lane, [2] warm tie-count passes (lanes with a solution index inside the stretch)
+__device__ unsigned long long g_jump_private_solves[4];
+#endif
+
 VRC_HD uint32_t f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
 VRC_HD float u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
 
@@ -132,12 +138,13 @@ VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// per-ray table of the Euclid runs (jump_rows_build): one dword per (binade row, axis pair),
-//   row = e - kJumpFirstBinade (0 <= row < kJumpBinades), pairs xy, xz, yz:   tab[(3 * (row % kJumpRing) + pair) * stride]
+// per-ray table of the Euclid runs (jump_rows_build): two dwords per (binade row, axis pair),
+//   row = e - kJumpFirstBinade (0 <= row < kJumpBinades), pairs xy, xz, yz:   tab[(2 * (3 * (row % kJumpRing) + pair) + {0, 1}) * stride]
 // A ray's intersection_t only grow, so it needs the row of the binade it is in and those ahead: the table is a ring of
 // kJumpRing rows, and `rows` (a bit per row, kept by the caller) says which rows it holds right now.
-//   bits 0-23  s: s * inc_a == g (mod inc_b), 0 <= s < inc_b        bits 24-31  g = gcd(inc_a, inc_b)
-//   g == 255: the gcd is 255 or more (the pair is solved afresh when it is needed: rare);  whole dword 0: no entry
+//   dword 0  s: s * inc_a == g (mod inc_b), 0 <= s < inc_b        dword 1  g = gcd(inc_a, inc_b);  g == 0: no entry
+// (Packed into one dword with 8 bits for g, the 0.4 % of the pairs whose gcd does not fit made 11 % of all pair evaluations
+// of the headline frame wait for an on-the-spot Euclid run of some lane of the wave.)
 // The increments depend on (delta_t, binade) only.  In HBM (RaycastParams::jump_cache), one table per lane, interleaved
 // over the 64 lanes of a wave (stride 64) so that a row is one coalesced 256-byte line.
 // ---------------------------------------------------------------------------------------------------------------
@@ -149,7 +156,7 @@ constexpr int kJumpBinades = 12;              // t < 2^19
 constexpr int kJumpRing = 4;                  // (the slot mask in jump_rows_build is written for 4)
 static_assert(kJumpRing == 4, "jump_rows_build: slot mask");
 constexpr int kJumpRingUnused = 0;                  // rows kept per ray: a ring indexed by row % kJumpRing (intersection_t only grows)
-constexpr int kJumpTableDwords = 3 * kJumpRing;
+constexpr int kJumpTableDwords = 6 * kJumpRing;   // (s, g) per pair and row
 
 // s and g with s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib; 1 <= ia, ib < 2^24.  Extended Euclid on exact integers
 // held in floats, two steps per trip with the roles of the two remainders alternating (no conditional swaps):
@@ -192,7 +199,7 @@ VRC_HD void pair_solve(bool active, int32_t ia, int32_t ib, int32_t &s_out, int3
     while (VRC_WAVE_ANY(euclid_busy(c))) euclid_step(c);
     euclid_finish(c, ib, s_out, g_out);
 }
-VRC_HD uint32_t jump_entry_pack(int32_t s, int32_t g) { return (uint32_t)s | ((uint32_t)(g < 255 ? g : 255) << 24); }
+struct JumpEntry { int32_t s, g; };            // g == 0: no entry
 
 // Builds one row (binade kJumpFirstBinade + row, the three pairs) of the table of every lane with `active` set; the
 // other lanes idle through the loop.  A pair one of whose axes cannot have a progression in that binade gets "no entry".
@@ -211,9 +218,10 @@ VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float
     if (active) {
         int32_t s, g;
         const int slot = row % kJumpRing;
-        euclid_finish(cxy, iy, s, g); tab[(3 * slot + 0) * stride] = vxy ? jump_entry_pack(s, g) : 0u;
-        euclid_finish(cxz, iz, s, g); tab[(3 * slot + 1) * stride] = vxz ? jump_entry_pack(s, g) : 0u;
-        euclid_finish(cyz, iz, s, g); tab[(3 * slot + 2) * stride] = vyz ? jump_entry_pack(s, g) : 0u;
+        uint32_t *row_at = tab + (6 * slot) * stride;
+        euclid_finish(cxy, iy, s, g); row_at[0 * stride] = (uint32_t)s; row_at[1 * stride] = vxy ? (uint32_t)g : 0u;
+        euclid_finish(cxz, iz, s, g); row_at[2 * stride] = (uint32_t)s; row_at[3 * stride] = vxz ? (uint32_t)g : 0u;
+        euclid_finish(cyz, iz, s, g); row_at[4 * stride] = (uint32_t)s; row_at[5 * stride] = vyz ? (uint32_t)g : 0u;
         solves += (vxy ? 1u : 0u) + (vxz ? 1u : 0u) + (vyz ? 1u : 0u);
     }
 }
@@ -251,13 +259,20 @@ VRC_HD void jump_rows_build(bool want, bool live, uint32_t &rows, float tx, floa
         need &= ~rows;
     }
 }
-VRC_HD uint32_t jump_table_entry(const uint32_t *tab, int stride, uint32_t rows, int pair, int32_t e) {
+VRC_HD JumpEntry jump_table_entry(const uint32_t *tab, int stride, uint32_t rows, int pair, int32_t e) {
     const uint32_t row = (uint32_t)(e - kJumpFirstBinade);
     const bool have = row < (uint32_t)kJumpBinades && ((rows >> (row & 31u)) & 1u);
+    JumpEntry en;
+    en.s = 0; en.g = 0;                                           // a row the table does not hold: "no entry"
 #ifdef VRC_JUMP_FAKE_TABLE   // (timing experiment only: no load, wrong tie counts)
-    return have ? ((1u << 24) | (12345u + (uint32_t)pair)) : 0u;
+    if (have) { en.s = 12345 + pair; en.g = 1; }
+    return en;
 #endif
-    return have ? tab[(3 * (int)(row % (uint32_t)kJumpRing) + pair) * stride] : 0u;   // a row the table does not hold: "no entry"
+    if (have) {
+        const uint32_t *at = tab + (2 * (3 * (int)(row % (uint32_t)kJumpRing) + pair)) * stride;
+        en.s = (int32_t)at[0]; en.g = (int32_t)at[stride];
+    }
+    return en;
 }
 
 // One regular axis pair in a common binade: the consumed events are Ma + i*ia (0 <= i < ma) and Mb + j*ib (0 <= j < mb),
@@ -266,10 +281,10 @@ VRC_HD uint32_t jump_table_entry(const uint32_t *tab, int stride, uint32_t rows,
 // pair_probe() is the hot half (one modular product, straight-line so that the three pairs of a jump overlap);
 // pair_count() the warm half, entered only when a solution index may lie inside the stretch.
 struct PairProbe { int32_t w, s, g; bool may; };
-VRC_HD PairProbe pair_probe(bool active, uint32_t entry, int32_t Ma, int32_t ma, int32_t Mb, int32_t ib) {
+VRC_HD PairProbe pair_probe(bool active, JumpEntry entry, int32_t Ma, int32_t ma, int32_t Mb, int32_t ib) {
     PairProbe p;
-    p.s = active ? (int32_t)(entry & 0xffffffu) : 0;
-    p.g = active ? (int32_t)(entry >> 24) : 1;
+    p.s = active ? entry.s : 0;
+    p.g = active ? entry.g : 1;
     const int32_t m = active ? ib : 64;
     // (c * s) mod m in [0, m): the 48-bit product is exact in fp64, its quotient estimate within 2^-20 of the true one
     const double dm = (double)m, prod = (double)(Mb - Ma) * (double)p.s;
@@ -305,20 +320,24 @@ VRC_HD PairTies pair_count(const PairProbe &p, int32_t Ma, int32_t ia, int32_t m
     }
     return out;
 }
-// a table dword that cannot be used as it is: no entry (below t = 128, beyond the table) or a gcd of 255 or more
-VRC_HD bool jump_entry_unusable(uint32_t entry) { return (uint32_t)((entry >> 24) - 1u) >= 254u; }
-VRC_HD PairTies pair_ties(bool active, uint32_t entry, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
-    const bool solve = active && jump_entry_unusable(entry);
-    int32_t g_solved = 1;
-    if (VRC_WAVE_ANY(solve)) {                                    // rare: a gcd >= 255, or a caller that keeps no table
-        int32_t s2;
-        pair_solve(solve, solve ? ia : 64, solve ? ib : 64, s2, g_solved);
-        if (solve) entry = (uint32_t)s2 | (1u << 24);             // (the solved g may not fit the dword: patched in below)
+VRC_HD PairTies pair_ties(bool active, JumpEntry entry, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
+    const bool solve = active && entry.g == 0;                    // no entry: below t = 128, beyond the table, evicted from the ring
+#if defined(VRC_SCHED_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    if (solve) atomicAdd(&g_jump_private_solves[0], 1ULL);
+    if (VRC_WAVE_ANY(solve) && active && !solve) atomicAdd(&g_jump_private_solves[1], 1ULL);
+#endif
+    if (VRC_WAVE_ANY(solve)) {                                    // rare: solved on the spot
+        int32_t s2, g2;
+        pair_solve(solve, solve ? ia : 64, solve ? ib : 64, s2, g2);
+        if (solve) { entry.s = s2; entry.g = g2; }
     }
-    PairProbe q = pair_probe(active, entry, Ma, ma, Mb, ib);
-    if (solve) { q.g = g_solved; q.may = (uint64_t)(uint32_t)q.w < (uint64_t)(uint32_t)ma * (uint64_t)(uint32_t)q.g; }
+    const PairProbe q = pair_probe(active, entry, Ma, ma, Mb, ib);
     PairTies out;
     out.count = 0; out.first_i = 0; out.step_i = 1;
+#if defined(VRC_SCHED_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    if (q.may) atomicAdd(&g_jump_private_solves[2], 1ULL);
+    if (VRC_WAVE_ANY(q.may) && active) atomicAdd(&g_jump_private_solves[3], 1ULL);
+#endif
     if (VRC_WAVE_ANY(q.may)) out = pair_count(q, Ma, ia, ma, Mb, ib, mb);   // warm: a solution index may lie inside the stretch
     return out;
 }
@@ -383,9 +402,9 @@ VRC_HD JumpOut stretch_jump(float &tx, float &ty, float &tz, float dx, float dy,
                             int32_t &nz, int32_t left, const uint32_t *tab, int stride, uint32_t rows) {
     // the table dwords first: their addresses need the exponents only, and the loads have the whole decode to arrive
     const int32_t ex0 = (int32_t)(f2u(tx) >> 23), ey0 = (int32_t)(f2u(ty) >> 23), ez0 = (int32_t)(f2u(tz) >> 23);
-    const uint32_t txy = (ex0 == ey0) ? jump_table_entry(tab, stride, rows, 0, ex0) : 0u;
-    const uint32_t txz = (ex0 == ez0) ? jump_table_entry(tab, stride, rows, 1, ex0) : 0u;
-    const uint32_t tyz = (ey0 == ez0) ? jump_table_entry(tab, stride, rows, 2, ey0) : 0u;
+    const JumpEntry txy = jump_table_entry(tab, stride, ex0 == ey0 ? rows : 0u, 0, ex0);
+    const JumpEntry txz = jump_table_entry(tab, stride, ex0 == ez0 ? rows : 0u, 1, ex0);
+    const JumpEntry tyz = jump_table_entry(tab, stride, ey0 == ez0 ? rows : 0u, 2, ey0);
     JumpAxis ax = jump_axis(tx, dx, nx), ay = jump_axis(ty, dy, ny), az = jump_axis(tz, dz, nz);
     float X = ax.E < ay.E ? ax.E : ay.E;
     X = X < az.E ? X : az.E;

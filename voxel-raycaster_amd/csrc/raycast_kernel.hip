@@ -764,13 +764,15 @@ namespace vrc {
 #ifdef VRC_SCHED_STATS
 }  // namespace vrc
 // profiling build only (tools/run_hist.py): read / clear the run-length histogram
-extern "C" int vrc_stats_run_hist(unsigned long long *out96, int clear) {   // out: 96 histogram + 8 jump counters
+extern "C" int vrc_stats_run_hist(unsigned long long *out96, int clear) {   // out: 96 histogram + 8 jump counters + 4 tie-path counters (108 values)
     if (out96 && hipMemcpyFromSymbol(out96, HIP_SYMBOL(vrc::g_run_hist), sizeof(vrc::g_run_hist)) != hipSuccess) return 1;
     if (out96 && hipMemcpyFromSymbol(out96 + 96, HIP_SYMBOL(vrc::g_jump_stats), sizeof(vrc::g_jump_stats)) != hipSuccess) return 1;
+    if (out96 && hipMemcpyFromSymbol(out96 + 104, HIP_SYMBOL(vrc::g_jump_private_solves), sizeof(vrc::g_jump_private_solves)) != hipSuccess) return 1;
     if (clear) {
         static unsigned long long zero[3][32];
         if (hipMemcpyToSymbol(HIP_SYMBOL(vrc::g_run_hist), zero, sizeof(zero)) != hipSuccess) return 1;
         if (hipMemcpyToSymbol(HIP_SYMBOL(vrc::g_jump_stats), zero, sizeof(vrc::g_jump_stats)) != hipSuccess) return 1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vrc::g_jump_private_solves), zero, sizeof(vrc::g_jump_private_solves)) != hipSuccess) return 1;
     }
     return 0;
 }
