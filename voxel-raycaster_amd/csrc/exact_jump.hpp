@@ -138,13 +138,14 @@ VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// per-ray table of the Euclid runs (jump_rows_build): two dwords per (binade row, axis pair),
-//   row = e - kJumpFirstBinade (0 <= row < kJumpBinades), pairs xy, xz, yz:   tab[(2 * (3 * (row % kJumpRing) + pair) + {0, 1}) * stride]
+// per-ray table of the Euclid runs (jump_rows_build): one dword per (binade row, axis pair),
+//   row = e - kJumpFirstBinade (0 <= row < kJumpBinades), pairs xy, xz, yz:   tab[(3 * (row % kJumpRing) + pair) * stride]
 // A ray's intersection_t only grow, so it needs the row of the binade it is in and those ahead: the table is a ring of
 // kJumpRing rows, and `rows` (a bit per row, kept by the caller) says which rows it holds right now.
-//   dword 0  s: s * inc_a == g (mod inc_b), 0 <= s < inc_b        dword 1  g = gcd(inc_a, inc_b);  g == 0: no entry
-// (Packed into one dword with 8 bits for g, the 0.4 % of the pairs whose gcd does not fit made 11 % of all pair evaluations
-// of the headline frame wait for an on-the-spot Euclid run of some lane of the wave.)
+//   bits 0-23  s: s * inc_a == g (mod inc_b), 0 <= s < inc_b        bits 24-31  g = gcd(inc_a, inc_b)
+//   g == 255: the gcd is 255 or more and the pair is solved afresh when it is needed (0.4 % of the pairs; with the full gcd
+//   in a second dword those on-the-spot runs disappear, but the wider rows cost as much as they save: 2.54-2.57 ms either
+//   way, 88 instead of 72 bytes of scratch, 1.0 instead of 0.67 GB of HBM traffic per frame);  whole dword 0: no entry
 // The increments depend on (delta_t, binade) only.  In HBM (RaycastParams::jump_cache), one table per lane, interleaved
 // over the 64 lanes of a wave (stride 64) so that a row is one coalesced 256-byte line.
 // ---------------------------------------------------------------------------------------------------------------
@@ -153,10 +154,8 @@ VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
 #endif
 constexpr int kJumpFirstBinade = 127 + VRC_JUMP_FIRST_LOG2;   // no table below t = 128: a binade of fewer voxels than a Euclid run costs
 constexpr int kJumpBinades = 12;              // t < 2^19
-constexpr int kJumpRing = 4;                  // (the slot mask in jump_rows_build is written for 4)
-static_assert(kJumpRing == 4, "jump_rows_build: slot mask");
-constexpr int kJumpRingUnused = 0;                  // rows kept per ray: a ring indexed by row % kJumpRing (intersection_t only grows)
-constexpr int kJumpTableDwords = 6 * kJumpRing;   // (s, g) per pair and row
+constexpr int kJumpRing = 4;                  // rows kept per ray: a ring indexed by row % kJumpRing (intersection_t only grows)
+constexpr int kJumpTableDwords = 3 * kJumpRing;   // one dword per pair and row
 
 // s and g with s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib; 1 <= ia, ib < 2^24.  Extended Euclid on exact integers
 // held in floats, two steps per trip with the roles of the two remainders alternating (no conditional swaps):
@@ -199,7 +198,8 @@ VRC_HD void pair_solve(bool active, int32_t ia, int32_t ib, int32_t &s_out, int3
     while (VRC_WAVE_ANY(euclid_busy(c))) euclid_step(c);
     euclid_finish(c, ib, s_out, g_out);
 }
-struct JumpEntry { int32_t s, g; };            // g == 0: no entry
+struct JumpEntry { int32_t s, g; };            // g == 0: no entry, g == 255: a gcd of 255 or more (solve on the spot)
+VRC_HD uint32_t jump_entry_pack(int32_t s, int32_t g) { return (uint32_t)s | ((uint32_t)(g < 255 ? g : 255) << 24); }
 
 // Builds one row (binade kJumpFirstBinade + row, the three pairs) of the table of every lane with `active` set; the
 // other lanes idle through the loop.  A pair one of whose axes cannot have a progression in that binade gets "no entry".
@@ -218,10 +218,9 @@ VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float
     if (active) {
         int32_t s, g;
         const int slot = row % kJumpRing;
-        uint32_t *row_at = tab + (6 * slot) * stride;
-        euclid_finish(cxy, iy, s, g); row_at[0 * stride] = (uint32_t)s; row_at[1 * stride] = vxy ? (uint32_t)g : 0u;
-        euclid_finish(cxz, iz, s, g); row_at[2 * stride] = (uint32_t)s; row_at[3 * stride] = vxz ? (uint32_t)g : 0u;
-        euclid_finish(cyz, iz, s, g); row_at[4 * stride] = (uint32_t)s; row_at[5 * stride] = vyz ? (uint32_t)g : 0u;
+        euclid_finish(cxy, iy, s, g); tab[(3 * slot + 0) * stride] = vxy ? jump_entry_pack(s, g) : 0u;
+        euclid_finish(cxz, iz, s, g); tab[(3 * slot + 1) * stride] = vxz ? jump_entry_pack(s, g) : 0u;
+        euclid_finish(cyz, iz, s, g); tab[(3 * slot + 2) * stride] = vyz ? jump_entry_pack(s, g) : 0u;
         solves += (vxy ? 1u : 0u) + (vxz ? 1u : 0u) + (vyz ? 1u : 0u);
     }
 }
@@ -256,6 +255,7 @@ VRC_HD void jump_rows_build(bool want, bool live, uint32_t &rows, float tx, floa
         const bool build = live && !((rows >> row) & 1u) && (((need >> row) & 1u) || (row >= lo_row && row - lo_row < kJumpRing));
         jump_table_build_row(build, row, dx, dy, dz, tab, stride, solves);
         if (build) rows = (rows & ~(0x11111111u << (row % kJumpRing))) | (1u << row);   // the rows that shared its ring slot are gone
+        static_assert(kJumpRing == 4, "the slot mask above has a bit every kJumpRing rows");
         need &= ~rows;
     }
 }
@@ -269,8 +269,8 @@ VRC_HD JumpEntry jump_table_entry(const uint32_t *tab, int stride, uint32_t rows
     return en;
 #endif
     if (have) {
-        const uint32_t *at = tab + (2 * (3 * (int)(row % (uint32_t)kJumpRing) + pair)) * stride;
-        en.s = (int32_t)at[0]; en.g = (int32_t)at[stride];
+        const uint32_t d = tab[(3 * (int)(row % (uint32_t)kJumpRing) + pair) * stride];
+        en.s = (int32_t)(d & 0xffffffu); en.g = (int32_t)(d >> 24);
     }
     return en;
 }
@@ -321,7 +321,7 @@ VRC_HD PairTies pair_count(const PairProbe &p, int32_t Ma, int32_t ia, int32_t m
     return out;
 }
 VRC_HD PairTies pair_ties(bool active, JumpEntry entry, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
-    const bool solve = active && entry.g == 0;                    // no entry: below t = 128, beyond the table, evicted from the ring
+    const bool solve = active && (entry.g == 0 || entry.g == 255);   // no entry (below t = 128, beyond the table, evicted) or a gcd >= 255
 #if defined(VRC_SCHED_STATS) && defined(__HIP_DEVICE_COMPILE__)
     if (solve) atomicAdd(&g_jump_private_solves[0], 1ULL);
     if (VRC_WAVE_ANY(solve) && active && !solve) atomicAdd(&g_jump_private_solves[1], 1ULL);

@@ -156,8 +156,19 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     if (kJump && tid == 0) {
         // the block's slot in the table buffer: tables exist for RESIDENT blocks only (they stay in the L2 / MALL), so a
         // block takes a free slot when it starts -- there are more slots than blocks the chip can hold -- and gives it back
-        unsigned i = (unsigned)(((unsigned long long)blockIdx.x * 2654435761ULL) % (unsigned)p.jump_slot_count);
-        while (atomicCAS(&p.jump_slots[i], 0u, 1u) != 0u) i = (i + 1u == (unsigned)p.jump_slot_count) ? 0u : i + 1u;
+        // Blocks go to the XCDs round-robin (blockIdx % 8), and each XCD has its own L2: a block looks for its slot in its
+        // XCD's eighth of the slots first, so that the 160 tables an XCD works on (2 MB) are lines its L2 already holds
+        // and rewrites in place -- the search wraps over all slots, so it always ends.
+        const unsigned n = (unsigned)p.jump_slot_count, per = n >> 3;
+        unsigned i = per ? (blockIdx.x & 7u) * per + (unsigned)(((unsigned long long)(blockIdx.x >> 3) * 2654435761ULL) % per)
+                         : (unsigned)(((unsigned long long)blockIdx.x * 2654435761ULL) % n);
+        const unsigned lo = per ? (blockIdx.x & 7u) * per : 0u, hi = per ? lo + per : n;
+        unsigned tries = 0;
+        while (atomicCAS(&p.jump_slots[i], 0u, 1u) != 0u) {
+            i++;
+            if (++tries < per) { if (i == hi) i = lo; }                   // first its own XCD's range ...
+            else if (i >= n) i = 0u;                                       // ... then anywhere
+        }
         s_jump_slot = (int)i;
     }
     __syncthreads();

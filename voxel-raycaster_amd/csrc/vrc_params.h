@@ -25,7 +25,7 @@ constexpr int kDefaultBurstSteps = 48, kDefaultShadeThreshold = 64, kDefaultSafe
 // depth from which they are on by default (measured: depth 10 loses 15 %, depth 12 gains 15 %, depth 16 is 3.3x faster)
 constexpr int kDefaultJumpMinRun = 96, kDefaultJumpMinDepth = 12;
 constexpr int kJumpOff = 1 << 24;      // jump_min_run >= this: the instances without the jump block
-constexpr int kJumpTableDwordsPerLane = 24;   // == kJumpTableDwords of exact_jump.hpp (checked in raycast_kernel.hip)
+constexpr int kJumpTableDwordsPerLane = 12;   // == kJumpTableDwords of exact_jump.hpp (checked in raycast_kernel.hip)
 constexpr int kJumpSlots = 2048;              // table slots for resident blocks (> 256 CUs x 5 blocks of the jump instances; a block takes one while it runs)
 constexpr int kMaxLights = 8;         // light slots (include/LightController.h:95)
 constexpr int kMaxLevels = 24;        // descriptor levels the LDS stack can hold (dim <= 2^24)
