@@ -73,7 +73,7 @@ for sname in a.scenes:
             if a.time:
                 row["phases"] = phase_times(c)
             if a.stats:
-                buf = (C.c_ulonglong * 108)()
+                buf = (C.c_ulonglong * 112)()
                 assert vrc.lib.vrc_stats_run_hist(buf, 1) == 0
                 assert c.compute()
                 assert vrc.lib.vrc_stats_run_hist(buf, 1) == 0
@@ -81,8 +81,8 @@ for sname in a.scenes:
                 row["jump_stats"] = dict(block_passes=js[0], lane_jumps=js[1], iterations_covered=js[2], left_node=js[3], capped=js[4],
                                          pair_solves=js[5], lanes_wanting=js[6], rounds=js[7],
                                          lanes_per_pass=round(js[1] / max(js[0], 1), 1), iters_per_jump=round(js[2] / max(js[1], 1), 1),
-                                         pairs_solved_on_the_spot=int(buf[104]), lanes_waiting_for_such_a_solve=int(buf[105]),
-                                         pairs_with_a_possible_tie=int(buf[106]), lanes_in_a_warm_tie_pass=int(buf[107]))
+                                         pairs_solved_on_the_spot=int(buf[108]), lanes_waiting_for_such_a_solve=int(buf[109]),
+                                         pairs_with_a_possible_tie=int(buf[110]), lanes_in_a_warm_tie_pass=int(buf[111]))
                 row["sched"] = c.scheduler_stats()
             print(json.dumps(row), flush=True)
     del c

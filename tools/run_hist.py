@@ -14,7 +14,7 @@ def hist(c, name, sets=()):
     for k, v in sets:
         assert c.add_to_settings_buffer(k, k.upper(), v)
     assert c.compute(), c.last_error()
-    buf = (C.c_ulonglong * 108)()     # 3 x 32 histogram + 8 jump counters
+    buf = (C.c_ulonglong * 112)()     # 3 x 32 histogram + 12 counters
     assert vrc.lib.vrc_stats_run_hist(buf, 1) == 0
     assert c.compute(), c.last_error()
     assert vrc.lib.vrc_stats_run_hist(buf, 1) == 0
@@ -33,7 +33,8 @@ def hist(c, name, sets=()):
               f"{h[1][b:].sum() / tot_s:.4f} | {int(h[2][b])} | {h[2][b:].sum() / tot_s:.4f} |")
     print(json.dumps({"scene": name, "sched": c.scheduler_stats(),
                       "jumps": dict(block_passes=js[0], lane_jumps=js[1], iterations_covered=js[2], left_node=js[3], capped=js[4],
-                                    pair_solves=js[5], lanes_wanting=js[6], rounds=js[7])}), flush=True)
+                                    pair_solves=js[5], lanes_wanting=js[6], rounds=js[7]),
+                      "safe_run": dict(wave_iterations=int(buf[105]), ungated_prefix_could_cover=int(buf[104]))}), flush=True)
 
 
 def device_caster(depth, w=1920, h=1080, thickness=2):
@@ -55,12 +56,13 @@ def device_caster(depth, w=1920, h=1080, thickness=2):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["d12", "d14", "d16"]
+    sets = [(a[6:].split("=")[0], int(a[6:].split("=")[1])) for a in sys.argv[1:] if a.startswith("--set=")]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["d12", "d14", "d16"]
     for w in which:
         d = int(w[1:])
         if d <= 13:
             c = bench.make_caster(bench.build_scene(d), 1920, 1080, 0)
         else:
             c = device_caster(d)
-        hist(c, f"depth {d}, 1920x1080, 1 light")
+        hist(c, f"depth {d}, 1920x1080, 1 light" + "".join(f", {k}={v}" for k, v in sets), sets)
         del c

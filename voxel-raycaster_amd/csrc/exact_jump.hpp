@@ -301,6 +301,21 @@ struct PairTies { int32_t count, first_i, step_i; };
 VRC_HD PairTies pair_count(const PairProbe &p, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
     PairTies out;
     out.count = 0; out.first_i = 0; out.step_i = 1;
+    // the usual case first: coprime increments and a stretch shorter than one period of the solutions (ma <= ib and
+    // mb <= ia): i0 = w is the only candidate, and it counts when its partner index j0 = (i0*ia - c) / ib (exact)
+    // lies in 0 .. mb-1.  (In the general form below k_a = 0, k_b = 0 or negative, k_lo = 0 or positive.)
+    const bool simple = p.g == 1 && ma <= ib && mb <= ia;
+#ifndef VRC_JUMP_NO_SIMPLE   // (A/B knob)
+    if (!VRC_WAVE_ANY(p.may && !simple)) {
+        if (p.may) {
+            int32_t rem;
+            const int32_t j0 = floordiv(mul24(p.w, ia) - (Mb - Ma), ib, recip_d(ib), rem);   // w < ma: w * ia < 2^24
+            out.count = (j0 >= 0 && j0 < mb) ? 1 : 0;
+            out.first_i = p.w; out.step_i = ib;
+        }
+        return out;
+    }
+#endif
     if (p.may) {
         const int32_t c = Mb - Ma, g = p.g;
         const double rg = recip_d(g);

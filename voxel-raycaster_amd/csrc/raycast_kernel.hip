@@ -123,7 +123,7 @@ enum LaneMode { kStep = 0, kEvent = 1, kShade = 2, kDone = 3, kRelight = 4 };
 __device__ unsigned long long g_run_hist[3][32];
 // [0] jump-block passes (waves)  [1] lane jumps  [2] iterations they covered  [3] jumps that left the node  [4] jumps that
 // ended at the step cap  [5] pair solves (extended Euclid)  [6] lanes that wanted a jump  [7] rounds
-__device__ unsigned long long g_jump_stats[8];
+__device__ unsigned long long g_jump_stats[12];   // [8], [9]: wave-iterations an ungated safe-run prefix could cover / all
 #endif
 #ifdef VRC_TIME_STATS
 // profiling build only: shader-clock ticks (s_memtime) a wave spends per phase of a round, summed over waves
@@ -423,6 +423,22 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             if (__ballot(gate.open) != 0ULL) {
                 const float x0 = r.itx, y0 = r.ity, z0 = r.itz;
                 float cnt = 0.0f, alive = 0.0f;
+#ifdef VRC_SCHED_STATS
+                // what a prefix without the per-iteration gate could cover: an open lane stays below its threshold for
+                // at least max over axes of floor((T - t) / delta_t) iterations; the wave could run the minimum of
+                // that over its open lanes (whole loop trips of it) with a constant 0/1 mask per lane
+                float kl = 3.0e38f;
+                if (gate.open) {
+                    const float T = fminf(fminf(safe_threshold(r.itx, r.dtx, nx), safe_threshold(r.ity, r.dty, ny)),
+                                          safe_threshold(r.itz, r.dtz, nz));
+                    kl = fmaxf(fmaxf(floorf((T - r.itx) * r.rdx * (r.rdx < 0 ? -1.0f : 1.0f)), floorf((T - r.ity) * fabsf(r.rdy))),
+                               floorf((T - r.itz) * fabsf(r.rdz)));
+                    kl = fmaxf(kl - 1.0f, 0.0f);
+                }
+                for (int o = 32; o > 0; o >>= 1) kl = fminf(kl, __shfl_xor(kl, o));
+                const int prefix_trips = (int)fminf(kl, 1.0e6f) / kSafeUnroll;
+                int trips_run = 0;
+#endif
 #pragma nounroll
                 for (int trip = safe_cap / kSafeUnroll; trip > 0; trip--) {
 #pragma unroll
@@ -440,10 +456,17 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                     VRC_STAT(w_iters, kSafeUnroll);
 #ifdef VRC_SCHED_STATS
                     if (lane_id == 0) l_try += kSafeUnroll;   // safe-run wave-iterations (reported as jump_attempts)
+                    trips_run++;
                     l_ok += kSafeUnroll * (unsigned)alive;    // ~ safe-run lane-iterations (jump_successes)
 #endif
                     if (__ballot(alive != 0.0f) == 0ULL) break;
                 }
+#ifdef VRC_SCHED_STATS
+                if (lane_id == 0) {
+                    atomicAdd(&g_jump_stats[8], (unsigned long long)((prefix_trips < trips_run ? prefix_trips : trips_run) * kSafeUnroll));
+                    atomicAdd(&g_jump_stats[9], (unsigned long long)(trips_run * kSafeUnroll));
+                }
+#endif
                 if (gate.open) {
                     nx -= safe_steps_taken(r.itx, x0, r.rdx);                // :560 as countdowns
                     ny -= safe_steps_taken(r.ity, y0, r.rdy);
@@ -775,10 +798,10 @@ namespace vrc {
 #ifdef VRC_SCHED_STATS
 }  // namespace vrc
 // profiling build only (tools/run_hist.py): read / clear the run-length histogram
-extern "C" int vrc_stats_run_hist(unsigned long long *out96, int clear) {   // out: 96 histogram + 8 jump counters + 4 tie-path counters (108 values)
+extern "C" int vrc_stats_run_hist(unsigned long long *out96, int clear) {   // out: 96 histogram + 12 counters + 4 tie-path counters (112 values)
     if (out96 && hipMemcpyFromSymbol(out96, HIP_SYMBOL(vrc::g_run_hist), sizeof(vrc::g_run_hist)) != hipSuccess) return 1;
     if (out96 && hipMemcpyFromSymbol(out96 + 96, HIP_SYMBOL(vrc::g_jump_stats), sizeof(vrc::g_jump_stats)) != hipSuccess) return 1;
-    if (out96 && hipMemcpyFromSymbol(out96 + 104, HIP_SYMBOL(vrc::g_jump_private_solves), sizeof(vrc::g_jump_private_solves)) != hipSuccess) return 1;
+    if (out96 && hipMemcpyFromSymbol(out96 + 108, HIP_SYMBOL(vrc::g_jump_private_solves), sizeof(vrc::g_jump_private_solves)) != hipSuccess) return 1;
     if (clear) {
         static unsigned long long zero[3][32];
         if (hipMemcpyToSymbol(HIP_SYMBOL(vrc::g_run_hist), zero, sizeof(zero)) != hipSuccess) return 1;
