@@ -38,6 +38,17 @@ def test_soak_slice_reference_kernel_against_the_oracle():
     assert totals.get("rgb_1e-5", 0) / n >= 0.999
 
 
+def test_soak_slice_exact_jumps_on_small_frames_of_deep_scenes():
+    """Fifteen seconds of tests/soak_jumps_gpu.py with a fixed seed: 640x360 frames (900 blocks: fewer than the chip holds,
+    the case in which blocks once handed their jump-table slots across XCDs and 1 frame in 4000 came back with a few
+    iteration counts off by one) of device-built depth-12 / 14 / 16 terrains, random poses, 1-4 lights, step caps and
+    jump thresholds -- image, hit records and every counter equal to the same frame stepped voxel by voxel."""
+    import soak_jumps_gpu
+    bad, frames, steps = soak_jumps_gpu.run(budget=15.0, seed=20261002, depths=(12, 14, 16))
+    assert frames >= 500 and steps > 1e11
+    assert bad == 0
+
+
 # ------------------------------------------------------------------ the array a reference host would pass
 @pytest.mark.parametrize("dim,density,seed", [(64, 0.5, 7), (128, 0.02, 5)], ids=["64^3-half-full", "128^3-sparse"])
 def test_strict_reference_buffer_through_both_branches(dim, density, seed, atlas):

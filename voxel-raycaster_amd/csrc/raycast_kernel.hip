@@ -146,6 +146,8 @@ __device__ unsigned long long g_time_stats[16];
 #ifndef VRC_MIN_BLOCKS_JUMP
 #define VRC_MIN_BLOCKS_JUMP (VRC_MIN_BLOCKS - 1)
 #endif
+// s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): (size - 1) << 11 | offset << 6 | register id 20; the XCD this wave runs on, 0..7
+constexpr int kHwRegXccId = (3 << 11) | (0 << 6) | 20;
 template <bool kJump, bool kMulti, bool kTuned>
 __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
@@ -155,19 +157,19 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     if (tid < kCtrCount) block_ctr[tid] = 0;
     if (kJump && tid == 0) {
         // the block's slot in the table buffer: tables exist for RESIDENT blocks only (they stay in the L2 / MALL), so a
-        // block takes a free slot when it starts -- there are more slots than blocks the chip can hold -- and gives it back
-        // Blocks go to the XCDs round-robin (blockIdx % 8), and each XCD has its own L2: a block looks for its slot in its
-        // XCD's eighth of the slots first, so that the 160 tables an XCD works on (2 MB) are lines its L2 already holds
-        // and rewrites in place -- the search wraps over all slots, so it always ends.
-        const unsigned n = (unsigned)p.jump_slot_count, per = n >> 3;
-        unsigned i = per ? (blockIdx.x & 7u) * per + (unsigned)(((unsigned long long)(blockIdx.x >> 3) * 2654435761ULL) % per)
-                         : (unsigned)(((unsigned long long)blockIdx.x * 2654435761ULL) % n);
-        const unsigned lo = per ? (blockIdx.x & 7u) * per : 0u, hi = per ? lo + per : n;
-        unsigned tries = 0;
+        // block takes a free slot when it starts and gives it back at its end.  The slots are divided among the XCDs and a
+        // block only ever takes one of the XCD it RUNS on (HW_REG_XCC_ID, not a guess from blockIdx): an XCD's L2 is not
+        // coherent with the others', so a slot handed from a block on one XCD to a block on another could be overwritten
+        // by the first L2's late write-back after the second block's lines were evicted (seen as 1 frame in 4000 with a
+        // few tie counts off by one when small frames made blocks look for slots anywhere; tests/soak_jumps_gpu.py).
+        // An eighth holds as many slots as an XCD holds blocks (vrc_api.cpp ensure_jump_cache), so the search always ends;
+        // the tables an XCD works on are lines its L2 already holds and rewrites in place.
+        const unsigned per = (unsigned)p.jump_slot_count >> 3;
+        const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(kHwRegXccId) & 7u;
+        const unsigned lo = xcc * per, hi = lo + per;
+        unsigned i = lo + (unsigned)(((unsigned long long)(blockIdx.x >> 3) * 2654435761ULL) % per);
         while (atomicCAS(&p.jump_slots[i], 0u, 1u) != 0u) {
-            i++;
-            if (++tries < per) { if (i == hi) i = lo; }                   // first its own XCD's range ...
-            else if (i >= n) i = 0u;                                       // ... then anywhere
+            if (++i == hi) i = lo;
         }
         s_jump_slot = (int)i;
     }

@@ -240,9 +240,10 @@ int install_viewport(vrc_caster *h, int32_t width, int32_t height, const float *
 // block SLOT.  Only resident blocks hold a slot (the kernel takes and returns them), so the buffer is sized for the chip,
 // not for the frame: at most kJumpSlots slots of 12 KB.
 int ensure_jump_cache(vrc_caster *h, int nblocks) {
-    const int slots = std::max(1, std::min(nblocks, vrc::kJumpSlots));
+    // an eighth of the slots per XCD, each eighth at least as large as the number of blocks one XCD can hold at a time
+    const int slots = 8 * std::max(1, std::min(nblocks, vrc::kJumpSlotsPerXcd));
     if (h->d_jump_cache && h->jump_slot_count >= slots) return VRC_OK;
-    release(h->d_jump_cache); release(h->d_jump_slots); h->jump_slot_count = 0; release(h->d_jump_slots);
+    release(h->d_jump_cache); release(h->d_jump_slots);
     h->jump_slot_count = 0;
     HIP_TRY(h, hipMalloc((void **)&h->d_jump_cache, (size_t)slots * vrc::kBlockThreads * vrc::kJumpTableDwordsPerLane * sizeof(uint32_t)));
     HIP_TRY(h, hipMalloc((void **)&h->d_jump_slots, (size_t)slots * sizeof(uint32_t)));

@@ -26,7 +26,8 @@ constexpr int kDefaultBurstSteps = 48, kDefaultShadeThreshold = 64, kDefaultSafe
 constexpr int kDefaultJumpMinRun = 96, kDefaultJumpMinDepth = 12;
 constexpr int kJumpOff = 1 << 24;      // jump_min_run >= this: the instances without the jump block
 constexpr int kJumpTableDwordsPerLane = 12;   // == kJumpTableDwords of exact_jump.hpp (checked in raycast_kernel.hip)
-constexpr int kJumpSlots = 2048;              // table slots for resident blocks (> 256 CUs x 5 blocks of the jump instances; a block takes one while it runs)
+constexpr int kJumpSlotsPerXcd = 256;         // table slots per XCD: 32 CUs x 8 blocks, the most 256-thread blocks an XCD can hold at any occupancy
+constexpr int kJumpSlots = 8 * kJumpSlotsPerXcd;   // a block takes a slot of ITS XCD while it runs (the L2s of two XCDs are not coherent)
 constexpr int kMaxLights = 8;         // light slots (include/LightController.h:95)
 constexpr int kMaxLevels = 24;        // descriptor levels the LDS stack can hold (dim <= 2^24)
 
