@@ -17,14 +17,17 @@ import voxel_raycaster_amd as vrc  # noqa: E402
 from run_hist import device_caster  # noqa: E402
 
 OFF = 1 << 24
+SIZES = [(64, 48), (200, 120), (320, 200), (640, 360), (640, 360), (1000, 600), (1920, 1080)]
 
 
-def run(budget=300.0, seed=1, depths=(12, 14, 16), w=640, h=360, only=None, dump=False):
+def run(budget=300.0, seed=1, depths=(12, 14, 16), w=640, h=360, only=None, dump=False, vary_size=False):
     """Returns (frames that differ, frames, lane steps covered).  only: render just these frame numbers of the seeded
-    sequence (replaying a run); dump: print the differing pixels with their hit records."""
+    sequence (replaying a run); dump: print the differing pixels with their hit records; vary_size: every caster gets a
+    new viewport now and then (64x48 .. 1920x1080: from a dozen blocks to several times what the chip holds)."""
     rng = np.random.default_rng(seed)
     t0, frames, bad, steps = time.time(), 0, 0, 0
     casters = {}
+    size_rng, sizes_used = np.random.default_rng(seed + 1), {(w, h)}
     index = -1
     while time.time() - t0 < budget and (only is None or index < max(only)):
         index += 1
@@ -51,6 +54,10 @@ def run(budget=300.0, seed=1, depths=(12, 14, 16), w=640, h=360, only=None, dump
         if only is not None and index not in only:
             continue
         c, cam, li = casters[depth]
+        if vary_size and size_rng.random() < 0.01:
+            nw, nh = SIZES[int(size_rng.integers(len(SIZES)))]
+            assert c.create_viewport(nw, nh) and c.validate(), c.last_error()
+            sizes_used.add((nw, nh))
         cam[0][:] = draws[0]
         cam[1][:] = pos
         li[:, 0:4] = draws[1] * 0.8 + 0.2
@@ -76,7 +83,8 @@ def run(budget=300.0, seed=1, depths=(12, 14, 16), w=640, h=360, only=None, dump
                     print("  pixel", int(x), int(y), "stepping", a[1][y, x].tolist(), a[0][y, x].tolist(), "| jumps", b[1][y, x].tolist(),
                           b[0][y, x].tolist(), flush=True)
                 print("  counters stepping", a[2], "| jumps", b[2], flush=True)
-    print(f"jump soak: {frames} frames of {w}x{h} at depths {list(depths)} (random pose, 1-4 lights, step cap, jump_min_run 16..1024): "
+    shapes = "/".join(f"{a}x{b}" for a, b in sorted(sizes_used))
+    print(f"jump soak: {frames} frames of {shapes} at depths {list(depths)} (random pose, 1-4 lights, step cap, jump_min_run 16..1024): "
           f"{bad} differ from the same frame without jumps; {steps / 1e12:.2f} T lane steps; {time.time() - t0:.0f} s")
     return bad, frames, steps
 
@@ -86,4 +94,4 @@ if __name__ == "__main__":
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     depths = tuple(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else (12, 14, 16)
     only = set(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else None      # replay: these frames only, with details
-    sys.exit(1 if run(budget, seed, depths, only=only, dump=only is not None)[0] else 0)
+    sys.exit(1 if run(budget, seed, depths, only=only, dump=only is not None, vary_size=only is None)[0] else 0)
