@@ -49,6 +49,25 @@ def test_soak_slice_exact_jumps_on_small_frames_of_deep_scenes():
     assert bad == 0
 
 
+def test_soak_slice_group_handle_against_the_single_handle():
+    """Eight seconds of tests/soak_groups_gpu.py with a fixed seed: 1-8 ranks on this GPU behind one handle (with and without
+    own copies of the tree), bands of 8..128 rows, frame sizes from 1x1 to 1920x1080 that are multiples of nothing, both
+    stepping modes, 1-4 lights, attachments, pinned and pageable read-back: frame, hit records, RGBA8 and counters equal
+    the single handle's."""
+    import soak_groups_gpu
+    bad, frames = soak_groups_gpu.run(budget=8.0, seed=20261002, depths=(8, 10))
+    assert frames >= 50 and bad == 0
+
+
+def test_soak_slice_device_builder_against_the_host_emitter():
+    """Eight seconds of tests/soak_builder_gpu.py with a fixed seed: column fields the fixtures do not hold (white noise,
+    slabs, cliffs, floating pillars, single layers, solid maps, ceilings) at depths 6-9: the device-built array equals the
+    host emitter's bit for bit, the device validate passes, point queries of the tree agree with the field."""
+    import soak_builder_gpu
+    bad, fields, descriptors = soak_builder_gpu.run(budget=8.0, seed=20261002, depths=(6, 7, 8, 9))
+    assert fields >= 10 and descriptors > 0 and bad == 0
+
+
 # ------------------------------------------------------------------ the array a reference host would pass
 @pytest.mark.parametrize("dim,density,seed", [(64, 0.5, 7), (128, 0.02, 5)], ids=["64^3-half-full", "128^3-sparse"])
 def test_strict_reference_buffer_through_both_branches(dim, density, seed, atlas):
