@@ -330,6 +330,17 @@ int vrc_build_heightfield(vrc_caster *h, uint32_t depth, const uint16_t *hi, con
 /* Host twin of vrc_build_heightfield (sequential emitter, depth <= 13): the array to compare the device build with. */
 int vrc_octree_from_columns(uint32_t depth, const uint16_t *hi, const uint16_t *lo, uint32_t layout, uint64_t **descriptors,
                             uint64_t *n_descriptors, uint64_t *root_index);
+/* The same builder for Octree::Generate's own input (src/map/Octree.cpp:13-43): a dense grid int8[dim^3],
+ * x + dim*(y + dim*z), any non-zero voxel solid -- the reference's Map::data (src/map/Map.cpp:7-30).  The grid crosses
+ * PCIe once; occupancy pyramid, count, emit and validate run in the handle's HBM and the tree is installed as the octree
+ * (materials: vrc_octree_attachments_from_grid on the array read back, or none).  3 <= depth <= 12 (4096^3 = 64 GiB).
+ * Bit-identical to vrc_octree_generate_ex(grid, dim, VRC_LAYOUT_NO_PAGE_HEADERS).  validate_samples: tree point queries
+ * against the grid, half of them on / next to solid voxels.                                                          */
+int vrc_build_dense_grid(vrc_caster *h, uint32_t depth, const int8_t *grid, uint32_t flags, uint64_t validate_samples,
+                         vrc_build_info *info);
+/* Host twin: vrc_octree_generate with the layout flags of vrc_scene_shell_terrain_ex (array sized exactly). */
+int vrc_octree_generate_ex(const int8_t *grid, uint32_t dim, uint32_t layout, uint64_t **descriptors,
+                           uint64_t *n_descriptors, uint64_t *root_index);
 /* Read descriptors [first, first + count) of the resident octree back to the host (tests, tools). */
 int vrc_read_descriptors(vrc_caster *h, uint64_t first, uint64_t count, uint64_t *out);
 int vrc_octree_size(vrc_caster *h, uint64_t *n_descriptors, uint64_t *root_index);

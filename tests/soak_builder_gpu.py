@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Long-running check of the device SVO builder (csrc/svo_builder_gpu.hip, vrc_build_heightfield) on column fields the
-test suite does not hold: white noise, slabs, cliffs, pillars over bare ground, one-voxel and solid maps, depths 6..11 --
-the array built in HBM against the sequential host emitter (vrc_octree_from_columns) bit for bit, the device-side
-Octree::Validate, and point queries of the finished tree (Octree::GetVoxel, src/map/Octree.cpp:45-158) against the field
-itself.  Not collected by pytest.  python tests/soak_builder_gpu.py [seconds] [seed]"""
+"""Long-running check of the device SVO builders (csrc/svo_builder_gpu.hip) on inputs the test suite does not hold.
+vrc_build_heightfield: column fields of white noise, slabs, cliffs, pillars over bare ground, one-voxel and solid maps,
+depths 6..11; vrc_build_dense_grid: dense grids of noise at densities from a few voxels to nearly solid, blobs, planes,
+empty and full maps, depths 3..8.  The array built in HBM against the sequential host emitter (vrc_octree_from_columns /
+vrc_octree_generate_ex) bit for bit, the device-side Octree::Validate, and point queries of the finished tree
+(Octree::GetVoxel, src/map/Octree.cpp:45-158) against the input itself.
+Not collected by pytest.  python tests/soak_builder_gpu.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -59,11 +61,85 @@ def field(rng, depth):
     return kind, hi, lo
 
 
+def grid(rng, depth):
+    dim = 1 << depth
+    kind = int(rng.integers(7))
+    if kind == 0:                                          # noise at any density
+        g = rng.random(dim ** 3) < 10.0 ** (-4.0 * rng.random())
+    elif kind == 1:                                        # a handful of voxels
+        g = np.zeros(dim ** 3, dtype=bool)
+        g[rng.integers(0, dim ** 3, int(rng.integers(1, 20)))] = True
+    elif kind == 2:                                        # nearly solid: a handful of holes
+        g = np.ones(dim ** 3, dtype=bool)
+        g[rng.integers(0, dim ** 3, int(rng.integers(0, 20)))] = False
+    elif kind == 3:                                        # blobs
+        zz, yy, xx = np.mgrid[0:dim, 0:dim, 0:dim]
+        g = np.zeros((dim, dim, dim), dtype=bool)
+        for _ in range(int(rng.integers(1, 6))):
+            cx, cy, cz = rng.random(3) * dim
+            g |= (xx - cx) ** 2 + (yy - cy) ** 2 + (zz - cz) ** 2 < (rng.random() * dim / 3) ** 2
+        g = g.reshape(-1)
+    elif kind == 4:                                        # axis-aligned planes and lines
+        g = np.zeros((dim, dim, dim), dtype=bool)
+        for _ in range(int(rng.integers(1, 5))):
+            a = int(rng.integers(3))
+            idx = [slice(None)] * 3
+            idx[a] = int(rng.integers(dim))
+            if rng.random() < 0.5:
+                idx[(a + 1) % 3] = int(rng.integers(dim))
+            g[tuple(idx)] = True
+        g = g.reshape(-1)
+    elif kind == 5:
+        g = np.zeros(dim ** 3, dtype=bool)
+    else:
+        g = np.ones(dim ** 3, dtype=bool)
+    return kind, (g.astype(np.int8) * int(rng.choice([1, 5, 6, -1])))
+
+
+def run_grid(rng):
+    depth = int(rng.integers(3, 9))
+    dim = 1 << depth
+    kind, g = grid(rng, depth)
+    host = vrc.Octree.Generate(g, dim, layout=2)
+    c = vrc.CLCaster()
+    assert c.init(0)
+    info = c.build_dense_grid(depth, g, validate_samples=1 << 18)
+    cnt, root = c.octree_size()
+    dev = c.read_descriptors()
+    same = (cnt == host.descriptor_buffer.size and root == host.root_index and np.array_equal(dev, host.descriptor_buffer)
+            and info["validate_mismatches"] == 0)
+    tree = vrc.Octree(dev, root, dim)
+    g3 = g.reshape(dim, dim, dim)
+    solid = np.argwhere(g3 != 0)
+    for i in range(200):
+        if i % 2 and len(solid):
+            z, y, x = (int(v) for v in solid[int(rng.integers(len(solid)))])
+            x = min(max(x + int(rng.integers(-1, 2)), 0), dim - 1)
+        else:
+            x, y, z = (int(v) for v in rng.integers(0, dim, 3))
+        if tree.GetVoxel((x, y, z))[0] != bool(g3[z, y, x]):
+            same = False
+            print("  GetVoxel", (x, y, z), "expected", bool(g3[z, y, x]), flush=True)
+            break
+    if not same:
+        print("MISMATCH grid depth", depth, "kind", kind, "descriptors host", host.descriptor_buffer.size, "device", cnt, "roots",
+              host.root_index, root, "validate", info["validate_mismatches"], flush=True)
+    return same, int(cnt)
+
+
 def run(budget=300.0, seed=1, depths=(6, 7, 8, 9, 10, 11)):
     """Returns (fields with a difference, fields, descriptors compared)."""
     rng = np.random.default_rng(seed)
     t0, n, bad, total = time.time(), 0, 0, 0
+    grids = 0
     while time.time() - t0 < budget:
+        if rng.random() < 0.4:
+            same, cnt = run_grid(rng)
+            n += 1
+            grids += 1
+            total += cnt
+            bad += 0 if same else 1
+            continue
         depth = int(rng.choice(depths))
         dim = 1 << depth
         kind, hi, lo = field(rng, depth)
@@ -93,8 +169,8 @@ def run(budget=300.0, seed=1, depths=(6, 7, 8, 9, 10, 11)):
             print("MISMATCH field", n - 1, "depth", depth, "kind", kind, "descriptors host", host.descriptor_buffer.size, "device", cnt,
                   "roots", host.root_index, root, "validate", info["validate_mismatches"], flush=True)
         del c
-    print(f"builder soak: {n} column fields of depth {list(depths)} (noise, slabs, thin shells, cliffs, pillars, single layers, solid, one voxel, "
-          f"ceilings, ramps): {bad} differ from the host emitter / the device validate / point queries; {total / 1e6:.1f} M descriptors; "
+    print(f"builder soak: {n - grids} column fields of depth {list(depths)} (noise, slabs, thin shells, cliffs, pillars, single layers, solid, one voxel, "
+          f"ceilings, ramps) and {grids} dense grids of depth 3..8 (noise at any density, single voxels, holes, blobs, planes, empty, solid): {bad} differ from the host emitter / the device validate / point queries; {total / 1e6:.1f} M descriptors; "
           f"{time.time() - t0:.0f} s")
     return bad, n, total
 

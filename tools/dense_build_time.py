@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Octree::Generate on a dense grid: the device builder (vrc_build_dense_grid) next to the sequential host emitter.
+python tools/dense_build_time.py [depths, default 8 9 10]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import voxel_raycaster_amd as vrc
+
+for depth in [int(v) for v in sys.argv[1:]] or [8, 9, 10]:
+    dim = 1 << depth
+    rng = np.random.default_rng(depth)
+    g = (rng.integers(0, 256, dim ** 3, dtype=np.uint8) < 5).astype(np.int8)          # 2 % noise ...
+    g.reshape(dim, dim, dim)[: dim // 8] = 5                                          # ... over a solid slab
+    t0 = time.time()
+    host = vrc.Octree.Generate(g, dim, layout=2)
+    t_host = time.time() - t0
+    c = vrc.CLCaster()
+    assert c.init(0)
+    c.build_dense_grid(depth, g)                                                      # warm-up (first launch of each kernel)
+    t0 = time.time()
+    info = c.build_dense_grid(depth, g, validate_samples=1 << 22)
+    t_dev = time.time() - t0
+    same = np.array_equal(c.read_descriptors(), host.descriptor_buffer)
+    print(json.dumps({"grid": f"{dim}^3 ({g.nbytes / 2**20:.0f} MiB), 2 % noise over a solid slab", "descriptors": int(info["n_descriptors"]),
+                      "host_emitter_s": round(t_host, 3), "device_call_s": round(t_dev, 3),
+                      "device_phases_s": {"upload+pyramid": round(info["seconds_height"], 3), "count": round(info["seconds_count"], 3),
+                                          "emit": round(info["seconds_emit"], 3)},
+                      "validate_mismatches": int(info["validate_mismatches"]), "bit_identical_to_host": bool(same)}), flush=True)

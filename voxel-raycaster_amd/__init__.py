@@ -120,6 +120,8 @@ SIGNATURES = {
     "vrc_build_heightfield": (C.c_int, [_H, C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_uint32, C.c_uint64,
                                        C.POINTER(BuildInfo)]),
     "vrc_octree_from_columns": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_uint32, C.POINTER(_u64p), _u64p, _u64p]),
+    "vrc_build_dense_grid": (C.c_int, [_H, C.c_uint32, _i8p, C.c_uint32, C.c_uint64, C.POINTER(BuildInfo)]),
+    "vrc_octree_generate_ex": (C.c_int, [_i8p, C.c_uint32, C.c_uint32, C.POINTER(_u64p), _u64p, _u64p]),
     "vrc_free": (None, [C.c_void_p]),
     "vrc_set_row_slice": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32]),
     "vrc_create_group": (C.c_int, [_i32p, C.c_int32, C.c_int32, C.POINTER(_H)]),
@@ -165,16 +167,21 @@ class Octree:
         self.attachment_buffer = None      # uint64[]               (Octree.h:49)
 
     @classmethod
-    def Generate(cls, data: np.ndarray, dim: int, buffer_size: int = 0, strict_reference: bool = True) -> "Octree":
-        """Octree::Generate (src/map/Octree.cpp:13-43).  data: int8[dim^3], x + dim*(y + dim*z)."""
+    def Generate(cls, data: np.ndarray, dim: int, buffer_size: int = 0, strict_reference: bool = True,
+                 layout: Optional[int] = None) -> "Octree":
+        """Octree::Generate (src/map/Octree.cpp:13-43).  data: int8[dim^3], x + dim*(y + dim*z).  layout (VRC_LAYOUT_* flags,
+        e.g. 2 = no page headers, what the device builders emit): vrc_octree_generate_ex, the array sized exactly."""
         data = np.ascontiguousarray(data, dtype=np.int8).reshape(-1)
         if data.size != dim ** 3:
             raise VrcError("grid size does not match dim^3")
         out = _u64p()
         n = C.c_uint64()
         root = C.c_uint64()
-        rc = lib.vrc_octree_generate(_ptr(data, _i8p), dim, buffer_size, int(strict_reference),
-                                     C.byref(out), C.byref(n), C.byref(root))
+        if layout is not None:
+            rc = lib.vrc_octree_generate_ex(_ptr(data, _i8p), dim, layout, C.byref(out), C.byref(n), C.byref(root))
+        else:
+            rc = lib.vrc_octree_generate(_ptr(data, _i8p), dim, buffer_size, int(strict_reference),
+                                         C.byref(out), C.byref(n), C.byref(root))
         if rc != 0:
             raise VrcError(f"vrc_octree_generate: {STATUS.get(rc, rc)}")
         arr = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
@@ -434,6 +441,20 @@ class CLCaster:
         u16 = C.POINTER(C.c_uint16)
         rc = lib.vrc_build_heightfield(self._h, depth, _ptr(hi, u16), _ptr(lo, u16) if lo is not None else None,
                                        BUILD_COUNT_ONLY if count_only else 0, validate_samples, C.byref(info))
+        if not self._ok(rc):
+            raise VrcError(self.last_error())
+        return info.as_dict()
+
+    def build_dense_grid(self, depth: int, grid: np.ndarray, count_only: bool = False, validate_samples: int = 0) -> dict:
+        """vrc_build_dense_grid: Octree::Generate's input (int8[dim^3], x + dim*(y + dim*z), non-zero = solid) built into the
+        SVO in HBM and installed as the octree.  Returns the build info; raises on failure."""
+        dim = 1 << depth
+        grid = np.ascontiguousarray(grid, dtype=np.int8).reshape(-1)
+        if grid.size != dim ** 3:
+            raise VrcError("grid size does not match dim^3")
+        info = BuildInfo()
+        rc = lib.vrc_build_dense_grid(self._h, depth, _ptr(grid, _i8p), BUILD_COUNT_ONLY if count_only else 0, validate_samples,
+                                      C.byref(info))
         if not self._ok(rc):
             raise VrcError(self.last_error())
         return info.as_dict()

@@ -345,6 +345,16 @@ int vrc_octree_generate(const int8_t *grid, uint32_t dim, uint64_t buffer_size, 
     return *descriptors ? VRC_OK : VRC_ERR_OUT_OF_MEMORY;
 }
 
+int vrc_octree_generate_ex(const int8_t *grid, uint32_t dim, uint32_t layout, uint64_t **descriptors, uint64_t *n_descriptors,
+                           uint64_t *root_index) {
+    if (!grid || !descriptors || !n_descriptors || !root_index || !is_pow2(dim)) return VRC_ERR_INVALID_ARGUMENT;
+    Emitter em((layout & VRC_LAYOUT_STRICT_REFERENCE) != 0, (layout & VRC_LAYOUT_NO_PAGE_HEADERS) == 0);
+    DenseSource src{grid, (int64_t)dim};
+    Node root = build(em, src, 0, 0, 0, (int)dim);
+    em.finish(root.desc, 0, descriptors, n_descriptors, root_index);
+    return *descriptors ? VRC_OK : VRC_ERR_OUT_OF_MEMORY;
+}
+
 int vrc_scene_shell_terrain_ex(uint32_t depth, uint64_t seed, int32_t thickness, int32_t octave_floor, uint32_t layout,
                                uint64_t **descriptors, uint64_t *n_descriptors, uint64_t *root_index, int32_t *height) {
     if (depth < 3 || depth > 16 || octave_floor < 0 || thickness < 0 || !descriptors || !n_descriptors || !root_index)

@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -79,27 +80,17 @@ __global__ void mip_kernel(const uint16_t *hi_prev, const uint16_t *lo_prev, uin
 
 __device__ __forceinline__ bool is_empty_leaf_masks(uint32_t masks) { return (masks & 0xffu) == 0 && (masks >> 8) == 0xffu; }
 
-// One candidate brick per thread: the emitter's recursion (svo_builder.cpp build<Source> + Emitter::place without
-// pages) as an iterative post-order walk.  kEmit = false counts slots, kEmit = true stores them.
-template <bool kEmit>
-__global__ __launch_bounds__(64) void brick_kernel(const Pyramid pyr, const BrickRef *__restrict__ bricks, uint32_t n_bricks, int kb,
-                                                   BrickInfo *__restrict__ info, const uint64_t *__restrict__ bases,
-                                                   uint64_t *__restrict__ desc, uint64_t total) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_bricks) return;
-    const int64_t dim = 1LL << pyr.depth;
-    const BrickRef ref = bricks[b];
-    const uint64_t base = kEmit ? bases[b] : 0;
-    int32_t k = 0;                                         // brick-local reversed coordinate = slots pushed so far
-    auto push = [&](uint64_t v) {
-        if (kEmit) desc[total - 1 - (base + (uint64_t)k)] = v;
-        k++;
-    };
-    auto certainly_empty = [&](int x, int y, int z, int size, int l) -> bool {
+// What a brick walk asks of the scene (the Source concept of svo_builder.cpp): is the cube of 2^l voxels at (x, y, z)
+// certainly empty, and which of the 2^3 voxels at (x, y, z) are solid.
+struct ColumnSrc {                            // columns solid for lo <= z <= hi, min / max pyramids over (x, y)
+    Pyramid pyr;
+    __device__ bool certainly_empty(int x, int y, int z, int size, int l) const {
+        const int64_t dim = 1LL << pyr.depth;
         const int64_t at = (int64_t)(x >> l) + (dim >> l) * (int64_t)(y >> l);
         return z > (int)pyr.hi[l][at] || z + size - 1 < (int)pyr.lo[l][at];
-    };
-    auto leaf_mask = [&](int x, int y, int z) -> uint32_t {
+    }
+    __device__ uint32_t leaf_mask(int x, int y, int z) const {
+        const int64_t dim = 1LL << pyr.depth;
         uint32_t m = 0;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -109,7 +100,37 @@ __global__ __launch_bounds__(64) void brick_kernel(const Pyramid pyr, const Bric
             if (z + 1 >= lo && z + 1 <= hi) m |= 1u << (c + 4);
         }
         return m;
+    }
+};
+constexpr int kMaxGridDepth = 12;             // a dense grid of 4096^3 bytes is 64 GiB
+struct GridSrc {                              // a dense grid (Octree::Generate's input, Octree.cpp:13-43) and its occupancy pyramid
+    const uint8_t *occ[kMaxGridDepth + 1];    // [1]: bit i = voxel i of the 2^3 block (i = x | y<<1 | z<<2); [l >= 2]: non-zero = a voxel inside
+    int depth;
+    __device__ int64_t at(int x, int y, int z, int l) const {
+        const int64_t d = (1LL << depth) >> l;
+        return (int64_t)(x >> l) + d * ((int64_t)(y >> l) + d * (int64_t)(z >> l));
+    }
+    __device__ bool certainly_empty(int x, int y, int z, int, int l) const { return occ[l][at(x, y, z, l)] == 0; }
+    __device__ uint32_t leaf_mask(int x, int y, int z) const { return occ[1][at(x, y, z, 1)]; }
+};
+
+// One candidate brick per thread: the emitter's recursion (svo_builder.cpp build<Source> + Emitter::place without
+// pages) as an iterative post-order walk.  kEmit = false counts slots, kEmit = true stores them.
+template <bool kEmit, class Src>
+__global__ __launch_bounds__(64) void brick_kernel(const Src src, const BrickRef *__restrict__ bricks, uint32_t n_bricks, int kb,
+                                                   BrickInfo *__restrict__ info, const uint64_t *__restrict__ bases,
+                                                   uint64_t *__restrict__ desc, uint64_t total) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bricks) return;
+    const BrickRef ref = bricks[b];
+    const uint64_t base = kEmit ? bases[b] : 0;
+    int32_t k = 0;                                         // brick-local reversed coordinate = slots pushed so far
+    auto push = [&](uint64_t v) {
+        if (kEmit) desc[total - 1 - (base + (uint64_t)k)] = v;
+        k++;
     };
+    auto certainly_empty = [&](int x, int y, int z, int size, int l) -> bool { return src.certainly_empty(x, y, z, size, l); };
+    auto leaf_mask = [&](int x, int y, int z) -> uint32_t { return src.leaf_mask(x, y, z); };
 
     uint32_t kept_masks[kMaxFrames][8];
     int32_t kept_k[kMaxFrames][8];
@@ -189,6 +210,23 @@ __global__ void scatter_kernel(const uint64_t *__restrict__ kv, uint64_t n, uint
     if (i < n) desc[total - 1 - kv[2 * i]] = kv[2 * i + 1];
 }
 
+// Octree::GetVoxel(position).found (src/map/Octree.cpp:45-158); the octant at each level is one bit of each coordinate.
+// (A first version kept the reference's running 64-bit box corner and compared against it: inside validate_grid_kernel that
+// form returned run-to-run different answers on a static tree -- hipcc 7.2, gfx950 -- while this one is stable; the
+// column validator never showed it.)
+__device__ __forceinline__ int tree_holds(const uint64_t *desc, uint64_t root_index, int depth, uint32_t x, uint32_t y, uint32_t z) {
+    uint64_t index = root_index, d = desc[index];
+    for (int l = depth - 1;; l--) {                            // l = log2 of the child's size
+        const uint32_t i = ((x >> l) & 1u) | (((y >> l) & 1u) << 1) | (((z >> l) & 1u) << 2);
+        if (!((d >> (16 + i)) & 1ULL)) return 0;
+        if (((d >> (24 + i)) & 1ULL) || l == 0) return 1;
+        const uint64_t at = index + (d & 0x7fffULL);
+        const uint64_t first = (d & kFarBit) ? desc[at] : at;
+        index = first + (uint64_t)(__popcll((d >> 16) & ((2ULL << i) - 1ULL)) - 1);
+        d = desc[index];
+    }
+}
+
 // Octree::Validate (src/map/Octree.cpp:329-352) on the device: GetVoxel(position).found against the procedural
 // occupancy, on pseudo-random voxels -- half of them within a few voxels of the shell, half anywhere in the column
 __global__ void validate_kernel(const Pyramid pyr, const uint64_t *__restrict__ desc, uint64_t root_index, uint64_t samples,
@@ -206,23 +244,7 @@ __global__ void validate_kernel(const Pyramid pyr, const uint64_t *__restrict__ 
     z = z < 0 ? 0 : (z >= dim ? dim - 1 : z);
     const int expect = z >= lo && z <= hi;
 
-    uint64_t index = root_index, d = desc[index];
-    int64_t half = dim / 2, cx = 0, cy = 0, cz = 0;
-    int found = 1;
-    for (;;) {
-        int i = 0;
-        if (x >= cx + half) { i |= 1; cx += half; }
-        if (y >= cy + half) { i |= 2; cy += half; }
-        if (z >= cz + half) { i |= 4; cz += half; }
-        if (!((d >> (16 + i)) & 1ULL)) { found = 0; break; }
-        if ((d >> (24 + i)) & 1ULL) break;
-        if (half == 1) break;
-        const uint64_t at = index + (d & 0x7fffULL);
-        const uint64_t first = (d & kFarBit) ? desc[at] : at;
-        index = first + (uint64_t)(__popcll((d >> 16) & ((2ULL << i) - 1ULL)) - 1);
-        d = desc[index];
-        half >>= 1;
-    }
+    const int found = tree_holds(desc, root_index, pyr.depth, (uint32_t)x, (uint32_t)y, (uint32_t)z);
     if (found != expect) atomicAdd(mismatches, 1ULL);
 }
 
@@ -233,6 +255,47 @@ __global__ void probe_kernel(const Pyramid pyr, const int32_t *xy, uint32_t n, i
     const int64_t at = (int64_t)xy[2 * i] + dim * (int64_t)xy[2 * i + 1];
     lohi[2 * i] = pyr.lo[0][at];
     lohi[2 * i + 1] = pyr.hi[0][at];
+}
+
+// ---- dense grids: occupancy pyramid.  Level 1 = the bottom-level valid mask of every 2^3 block (Octree.cpp:195-211: any
+// non-zero voxel is solid), level l >= 2 = "a voxel inside this 2^l cube"
+__global__ void occ1_kernel(const int8_t *__restrict__ grid, uint8_t *__restrict__ occ1, int64_t dim) {
+    const int64_t d = dim >> 1;
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= d) return;
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int64_t at = (2 * x + (i & 1)) + dim * ((2 * y + ((i >> 1) & 1)) + dim * (2 * z + ((i >> 2) & 1)));
+        if (grid[at]) m |= 1u << i;
+    }
+    occ1[x + d * (y + d * z)] = (uint8_t)m;
+}
+__global__ void occ_up_kernel(const uint8_t *__restrict__ prev, uint8_t *__restrict__ out, int64_t d) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= d) return;
+    const int64_t pd = 2 * d;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) any |= prev[(2 * x + (i & 1)) + pd * ((2 * y + ((i >> 1) & 1)) + pd * (2 * z + ((i >> 2) & 1)))];
+    out[x + d * (y + d * z)] = any ? 1 : 0;
+}
+// Octree::Validate against the grid itself: uniformly random voxels, and -- so that a sparse grid is probed where it
+// holds something -- the first solid voxel within 64 steps along +x of a random one, with the voxel in front of it
+__global__ void validate_grid_kernel(const int8_t *__restrict__ grid, int depth, const uint64_t *__restrict__ desc, uint64_t root_index,
+                                     uint64_t samples, uint64_t seed, unsigned long long *mismatches) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= samples) return;
+    const int64_t dim = 1LL << depth;
+    const uint64_t r = splitmix64(seed ^ splitmix64(s));
+    int64_t x = (int64_t)(r & (uint64_t)(dim - 1)), y = (int64_t)((r >> 20) & (uint64_t)(dim - 1)), z = (int64_t)((r >> 40) & (uint64_t)(dim - 1));
+    if (s & 1) {
+        for (int k = 0; k < 64 && x + 1 < dim && !grid[x + dim * (y + dim * z)]; k++) x++;
+        if ((s & 2) && x > 0) x--;
+    }
+    const int expect = grid[x + dim * (y + dim * z)] != 0;
+    const int found = tree_holds(desc, root_index, depth, (uint32_t)x, (uint32_t)y, (uint32_t)z);
+    if (found != expect) atomicAdd(mismatches, 1ULL);
 }
 
 // ---- the levels above the bricks, on the host (sequential, a few million nodes at most)
@@ -270,26 +333,22 @@ struct TopEmitter {
 };
 
 struct TopContext {
-    int depth, kb;
-    int64_t cells;                              // bricks per side
-    const std::vector<std::vector<uint16_t>> *hi, *lo;   // host copies of pyramid levels kb..depth (index l - kb)
-    const std::vector<int32_t> *cell_z0, *cell_n;
-    const std::vector<uint32_t> *cell_first;
+    int kb;
     const std::vector<BrickInfo> *info;
     std::vector<uint64_t> *bases;
     TopEmitter *em;
+    std::function<bool(int, int, int, int, int)> region_empty;   // (x, y, z, size, level): certainly no voxel inside
+    std::function<int64_t(int, int, int)> brick_at;              // candidate brick at voxel (x, y, z), -1: none (empty)
 };
 
 TopNode top_build(TopContext &c, int x, int y, int z, int size, int l) {
     TopNode self;
     if (l == c.kb) {                            // a brick: result of the count pass
-        const size_t cell = (size_t)(x >> c.kb) + (size_t)c.cells * (size_t)(y >> c.kb);
-        const int bz = z >> c.kb, z0 = (*c.cell_z0)[cell];
-        if (bz < z0 || bz >= z0 + (*c.cell_n)[cell]) { self.desc = kLeafAll; return self; }
-        const uint32_t b = (*c.cell_first)[cell] + (uint32_t)(bz - z0);
-        const BrickInfo &bi = (*c.info)[b];
+        const int64_t b = c.brick_at(x, y, z);
+        if (b < 0) { self.desc = kLeafAll; return self; }
+        const BrickInfo &bi = (*c.info)[(size_t)b];
         self.desc = (uint64_t)bi.masks << 16;
-        (*c.bases)[b] = (uint64_t)c.em->k;
+        (*c.bases)[(size_t)b] = (uint64_t)c.em->k;
         c.em->k += bi.size;
         self.k = bi.size ? c.em->k - 1 : -1;
         return self;
@@ -300,11 +359,8 @@ TopNode top_build(TopContext &c, int x, int y, int z, int size, int l) {
     for (int i = 0; i < 8; i++) {
         const int cx = x + ((i & 1) ? h : 0), cy = y + ((i & 2) ? h : 0), cz = z + ((i & 4) ? h : 0);
         TopNode child;
-        const int cl = l - 1;
-        const int64_t d = (int64_t)1 << (c.depth - cl);
-        const size_t at = (size_t)(cx >> cl) + (size_t)d * (size_t)(cy >> cl);
-        if (cz > (int)(*c.hi)[cl - c.kb][at] || cz + h - 1 < (int)(*c.lo)[cl - c.kb][at]) child.desc = kLeafAll;
-        else child = top_build(c, cx, cy, cz, h, cl);
+        if (c.region_empty(cx, cy, cz, h, l - 1)) child.desc = kLeafAll;
+        else child = top_build(c, cx, cy, cz, h, l - 1);
         if ((child.desc & kValidAll) == 0 && (child.desc & kLeafAll) == kLeafAll) {
             self.desc |= 1ULL << (i + 24);
         } else {
@@ -418,7 +474,7 @@ int build_columns_device(hipStream_t stream, uint32_t depth, uint64_t seed, int3
         GB_TRY(hipMalloc((void **)&d_bases, (size_t)nb * sizeof(uint64_t)));
         temp_bytes += (size_t)nb * (sizeof(BrickRef) + sizeof(BrickInfo) + sizeof(uint64_t));
         GB_TRY(hipMemcpyAsync(d_bricks, bricks.data(), (size_t)nb * sizeof(BrickRef), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL((brick_kernel<false>), dim3((nb + 63) / 64), dim3(64), 0, stream, pyr, (const BrickRef *)d_bricks, nb, kb, d_info,
+        hipLaunchKernelGGL((brick_kernel<false, ColumnSrc>), dim3((nb + 63) / 64), dim3(64), 0, stream, ColumnSrc{pyr}, (const BrickRef *)d_bricks, nb, kb, d_info,
                            (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0);
         GB_TRY(hipGetLastError());
         info.resize(nb);
@@ -428,7 +484,17 @@ int build_columns_device(hipStream_t stream, uint32_t depth, uint64_t seed, int3
 
         // 3. the levels above the bricks: brick bases in emission order + the top-level slots
         bases.assign(nb, 0);
-        TopContext ctx{(int)depth, kb, cells, &h_hi, &h_lo, &cell_z0, &cell_n, &cell_first, &info, &bases, &em};
+        TopContext ctx{kb, &info, &bases, &em,
+                       [&](int cx, int cy, int cz, int h, int cl) {
+                           const size_t at = (size_t)(cx >> cl) + (size_t)(dim >> cl) * (size_t)(cy >> cl);
+                           return cz > (int)h_hi[cl - kb][at] || cz + h - 1 < (int)h_lo[cl - kb][at];
+                       },
+                       [&](int x, int y, int z) -> int64_t {
+                           const size_t cell = (size_t)(x >> kb) + (size_t)cells * (size_t)(y >> kb);
+                           const int bz = z >> kb, z0 = cell_z0[cell];
+                           if (bz < z0 || bz >= z0 + cell_n[cell]) return -1;
+                           return (int64_t)cell_first[cell] + (bz - z0);
+                       }};
         const TopNode root = top_build(ctx, 0, 0, 0, (int)dim, (int)depth);
         em.push(root.desc | 1);                               // Octree.cpp:27-31
         total = (uint64_t)em.k;
@@ -445,7 +511,7 @@ int build_columns_device(hipStream_t stream, uint32_t depth, uint64_t seed, int3
         temp_bytes += em.kv.size() * sizeof(uint64_t);
         GB_TRY(hipMemcpyAsync(d_bases, bases.data(), (size_t)nb * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         GB_TRY(hipMemcpyAsync(d_kv, em.kv.data(), em.kv.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL((brick_kernel<true>), dim3((nb + 63) / 64), dim3(64), 0, stream, pyr, (const BrickRef *)d_bricks, nb, kb, d_info,
+        hipLaunchKernelGGL((brick_kernel<true, ColumnSrc>), dim3((nb + 63) / 64), dim3(64), 0, stream, ColumnSrc{pyr}, (const BrickRef *)d_bricks, nb, kb, d_info,
                            (const uint64_t *)d_bases, desc, total);
         {
             const uint64_t n = em.kv.size() / 2;
@@ -492,6 +558,165 @@ cleanup:
     if (out) *out = bi;
     (void)hipFree(d_hi); (void)hipFree(d_lo); (void)hipFree(d_bricks); (void)hipFree(d_info); (void)hipFree(d_bases);
     (void)hipFree(d_kv); (void)hipFree(d_mis); (void)hipFree(d_pxy); (void)hipFree(d_plohi);
+    if (desc) (void)hipFree(desc);
+    return rc;
+}
+
+// The same pipeline for Octree::Generate's own input (src/map/Octree.cpp:13-43: a dense grid, x + dim * (y + dim * z), any
+// non-zero voxel solid): the grid goes to the device once, an occupancy pyramid replaces the min / max pyramids, every
+// 64^3 brick that holds a voxel is a candidate.  On success *d_desc owns the array.
+int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_grid, uint32_t flags, uint64_t validate_samples,
+                      uint64_t **d_desc, vrc_build_info *out, std::string &error) {
+    int rc = VRC_OK;
+    vrc_build_info bi;
+    memset(&bi, 0, sizeof(bi));
+    (void)hipGetLastError();
+    const int64_t dim = 1LL << depth;
+    const int kb = std::min<int>(kBrickLog2, (int)depth);
+    const int64_t cells = dim >> kb;
+    int8_t *d_grid = nullptr;
+    uint8_t *d_occ = nullptr;
+    BrickRef *d_bricks = nullptr;
+    BrickInfo *d_info = nullptr;
+    uint64_t *d_bases = nullptr, *d_kv = nullptr, *desc = nullptr;
+    unsigned long long *d_mis = nullptr;
+    GridSrc src;
+    memset(&src, 0, sizeof(src));
+    src.depth = (int)depth;
+    std::vector<std::vector<uint8_t>> h_occ;            // host copies of levels kb..depth (index l - kb)
+    std::vector<int32_t> brick_index;
+    std::vector<BrickRef> bricks;
+    std::vector<BrickInfo> info;
+    std::vector<uint64_t> bases;
+    TopEmitter em;
+    uint64_t total = 0, temp_bytes = 0;
+    const double t0 = now_s();
+    double t1 = t0, t2 = t0, t3 = t0;
+    *d_desc = nullptr;
+
+    {
+        // 1. the grid and its occupancy pyramid
+        const size_t voxels = (size_t)dim * (size_t)dim * (size_t)dim;
+        size_t entries = 0;
+        std::vector<size_t> off(depth + 1, 0);
+        for (uint32_t l = 1; l <= depth; l++) { off[l] = entries; const size_t d = (size_t)(dim >> l); entries += d * d * d; }
+        GB_TRY(hipMalloc((void **)&d_grid, voxels));
+        GB_TRY(hipMalloc((void **)&d_occ, entries));
+        temp_bytes = voxels + entries;
+        GB_TRY(hipMemcpyAsync(d_grid, host_grid, voxels, hipMemcpyHostToDevice, stream));
+        src.occ[0] = (const uint8_t *)d_grid;
+        for (uint32_t l = 1; l <= depth; l++) src.occ[l] = d_occ + off[l];
+        {
+            const int64_t d = dim >> 1;
+            hipLaunchKernelGGL(occ1_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)d, (unsigned)d), dim3(256), 0, stream,
+                               (const int8_t *)d_grid, d_occ + off[1], dim);
+        }
+        for (uint32_t l = 2; l <= depth; l++) {
+            const int64_t d = dim >> l;
+            hipLaunchKernelGGL(occ_up_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)d, (unsigned)d), dim3(256), 0, stream,
+                               (const uint8_t *)(d_occ + off[l - 1]), d_occ + off[l], d);
+        }
+        GB_TRY(hipGetLastError());
+        h_occ.resize(depth - kb + 1);
+        for (uint32_t l = (uint32_t)kb; l <= depth; l++) {
+            const size_t d = (size_t)(dim >> l), n = d * d * d;
+            h_occ[l - kb].resize(n);
+            GB_TRY(hipMemcpyAsync(h_occ[l - kb].data(), src.occ[l], n, hipMemcpyDeviceToHost, stream));
+        }
+        GB_TRY(hipStreamSynchronize(stream));
+        t1 = now_s();
+
+        // 2. candidate bricks (in x, y, z order), count pass
+        brick_index.assign((size_t)(cells * cells * cells), -1);
+        for (size_t c = 0; c < brick_index.size(); c++)
+            if (h_occ[0][c]) {
+                brick_index[c] = (int32_t)bricks.size();
+                bricks.push_back(BrickRef{(uint16_t)(c % (size_t)cells), (uint16_t)((c / (size_t)cells) % (size_t)cells),
+                                          (uint16_t)(c / (size_t)(cells * cells)), 0});
+            }
+        const uint32_t nb = (uint32_t)bricks.size();
+        bi.n_bricks = nb;
+        if (nb) {
+            GB_TRY(hipMalloc((void **)&d_bricks, (size_t)nb * sizeof(BrickRef)));
+            GB_TRY(hipMalloc((void **)&d_info, (size_t)nb * sizeof(BrickInfo)));
+            GB_TRY(hipMalloc((void **)&d_bases, (size_t)nb * sizeof(uint64_t)));
+            temp_bytes += (size_t)nb * (sizeof(BrickRef) + sizeof(BrickInfo) + sizeof(uint64_t));
+            GB_TRY(hipMemcpyAsync(d_bricks, bricks.data(), (size_t)nb * sizeof(BrickRef), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL((brick_kernel<false, GridSrc>), dim3((nb + 63) / 64), dim3(64), 0, stream, src, (const BrickRef *)d_bricks, nb, kb,
+                               d_info, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0);
+            GB_TRY(hipGetLastError());
+            info.resize(nb);
+            GB_TRY(hipMemcpyAsync(info.data(), d_info, (size_t)nb * sizeof(BrickInfo), hipMemcpyDeviceToHost, stream));
+            GB_TRY(hipStreamSynchronize(stream));
+        }
+        t2 = now_s();
+
+        // 3. the levels above the bricks
+        bases.assign(nb, 0);
+        TopContext ctx{kb, &info, &bases, &em,
+                       [&](int cx, int cy, int cz, int, int cl) {
+                           const size_t d = (size_t)(dim >> cl);
+                           return h_occ[cl - kb][(size_t)(cx >> cl) + d * ((size_t)(cy >> cl) + d * (size_t)(cz >> cl))] == 0;
+                       },
+                       [&](int x, int y, int z) -> int64_t {
+                           return brick_index[(size_t)(x >> kb) + (size_t)cells * ((size_t)(y >> kb) + (size_t)cells * (size_t)(z >> kb))];
+                       }};
+        const TopNode root = top_build(ctx, 0, 0, 0, (int)dim, (int)depth);
+        em.push(root.desc | 1);                               // Octree.cpp:27-31
+        total = (uint64_t)em.k;
+        for (size_t at : em.far_fixups) em.kv[at] = total - 1 - em.kv[at];
+        bi.n_descriptors = total;
+        bi.root_index = 0;
+        bi.n_top_slots = em.kv.size() / 2;
+        bi.n_far_pointers_top = em.n_far;
+        if (flags & VRC_BUILD_COUNT_ONLY) goto finish;
+
+        // 4. emit
+        GB_TRY(hipMalloc((void **)&desc, total * sizeof(uint64_t)));
+        GB_TRY(hipMalloc((void **)&d_kv, em.kv.size() * sizeof(uint64_t)));
+        temp_bytes += em.kv.size() * sizeof(uint64_t);
+        if (nb) {
+            GB_TRY(hipMemcpyAsync(d_bases, bases.data(), (size_t)nb * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL((brick_kernel<true, GridSrc>), dim3((nb + 63) / 64), dim3(64), 0, stream, src, (const BrickRef *)d_bricks, nb, kb,
+                               d_info, (const uint64_t *)d_bases, desc, total);
+        }
+        GB_TRY(hipMemcpyAsync(d_kv, em.kv.data(), em.kv.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        {
+            const uint64_t n = em.kv.size() / 2;
+            hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint64_t *)d_kv, n, desc, total);
+        }
+        GB_TRY(hipGetLastError());
+        GB_TRY(hipStreamSynchronize(stream));
+        t3 = now_s();
+
+        if (validate_samples) {
+            GB_TRY(hipMalloc((void **)&d_mis, sizeof(unsigned long long)));
+            GB_TRY(hipMemsetAsync(d_mis, 0, sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL(validate_grid_kernel, dim3((unsigned)((validate_samples + 255) / 256)), dim3(256), 0, stream,
+                               (const int8_t *)d_grid, (int)depth, (const uint64_t *)desc, (uint64_t)0, validate_samples, (uint64_t)0x5eedULL, d_mis);
+            GB_TRY(hipGetLastError());
+            unsigned long long mis = 0;
+            GB_TRY(hipMemcpyAsync(&mis, d_mis, sizeof(mis), hipMemcpyDeviceToHost, stream));
+            GB_TRY(hipStreamSynchronize(stream));
+            bi.validate_samples = validate_samples;
+            bi.validate_mismatches = mis;
+        }
+    }
+finish:
+    bi.seconds_height = t1 - t0;
+    bi.seconds_count = t2 - t1;
+    bi.seconds_emit = (flags & VRC_BUILD_COUNT_ONLY) ? 0.0 : t3 - t2;
+    bi.seconds_total = now_s() - t0;
+    bi.device_bytes_peak = temp_bytes + total * sizeof(uint64_t) * ((flags & VRC_BUILD_COUNT_ONLY) ? 0 : 1);
+    bi.host_bytes = bricks.size() * (sizeof(BrickRef) + sizeof(BrickInfo) + sizeof(uint64_t)) + em.kv.size() * sizeof(uint64_t) +
+                    brick_index.size() * 4;
+    *d_desc = desc;
+    desc = nullptr;
+
+cleanup:
+    if (out) *out = bi;
+    (void)hipFree(d_grid); (void)hipFree(d_occ); (void)hipFree(d_bricks); (void)hipFree(d_info); (void)hipFree(d_bases);
+    (void)hipFree(d_kv); (void)hipFree(d_mis);
     if (desc) (void)hipFree(desc);
     return rc;
 }
