@@ -25,6 +25,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -38,7 +39,7 @@ namespace vrc {
 namespace {
 
 constexpr int kMaxDepth = 16;
-constexpr int kBrickLog2 = 6;             // bricks of 64^3 voxels
+constexpr int kBrickLog2 = 6;             // largest brick: 64^3 voxels (the walk's frame arrays); the builders use 32^3 / 16^3
 constexpr int kMaxFrames = kBrickLog2;    // node sizes 2^kb .. 4
 constexpr uint64_t kFarBit = 0x8000ULL, kLeafAll = 0xFF000000ULL, kValidAll = 0x00FF0000ULL;
 
@@ -402,7 +403,10 @@ int build_columns_device(hipStream_t stream, uint32_t depth, uint64_t seed, int3
     memset(&bi, 0, sizeof(bi));
     (void)hipGetLastError();                 // the launch checks below must not pick up an error an earlier call left behind
     const int64_t dim = 1LL << depth;
-    const int kb = std::min<int>(kBrickLog2, (int)depth);
+    // bricks of 32^3 voxels (one walk = one thread): measured 64^3 / 32^3 / 16^3 on the 198 GB scene of BASELINE configs[4]
+    // (depth 16, thickness 33): 12.1 / 5.8 / 5.6 s with 0.19 / 0.79 / 3.9 GB of host tables; depth 12: 43 / 16 / 13 ms
+    static const int column_brick_log2 = getenv("VRC_COLUMN_BRICK_LOG2") ? atoi(getenv("VRC_COLUMN_BRICK_LOG2")) : 5;
+    const int kb = std::min<int>(std::min(std::max(column_brick_log2, 2), kBrickLog2), (int)depth);
     const int64_t cells = dim >> kb;
     uint16_t *d_hi = nullptr, *d_lo = nullptr;
     BrickRef *d_bricks = nullptr;
@@ -572,7 +576,10 @@ int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_gri
     memset(&bi, 0, sizeof(bi));
     (void)hipGetLastError();
     const int64_t dim = 1LL << depth;
-    const int kb = std::min<int>(kBrickLog2, (int)depth);
+    // bricks of 16^3 voxels here: a dense grid is at most 4096^3, so the host's top levels stay small (256^3 cells), and a
+    // brick walk -- one thread -- is at most 585 descriptors instead of 37 449 (64^3: 0.05 s per pass whatever the grid)
+    static const int grid_brick_log2 = getenv("VRC_GRID_BRICK_LOG2") ? atoi(getenv("VRC_GRID_BRICK_LOG2")) : 4;
+    const int kb = std::min<int>(std::min(std::max(grid_brick_log2, 2), kBrickLog2), (int)depth);
     const int64_t cells = dim >> kb;
     int8_t *d_grid = nullptr;
     uint8_t *d_occ = nullptr;
