@@ -191,7 +191,10 @@ def test_device_dense_grid_builder_equals_the_host_emitter(depth, density, atlas
         assert c.build_dense_grid(depth, g, count_only=True)["n_descriptors"] == n
     # the last grid, rendered straight from the device-built tree
     w, h, md = 96, 64, 3 * dim
-    cam_pos, cam_dir = (dim * 0.5 + 0.3, -2.7, dim * 0.6 + 0.2), (1.7, 1.6)
+    g3 = g.reshape(dim, dim, dim)                                  # the camera sits in the empty voxel nearest to the centre
+    empty = np.argwhere(g3 == 0)                                   # (rays that start outside the map end at once, :563)
+    cz, cy, cx = empty[np.abs(empty - dim // 2).sum(1).argmin()] if len(empty) else (dim // 2,) * 3
+    cam_pos, cam_dir = (float(cx) + 0.3, float(cy) + 0.6, float(cz) + 0.2), (1.7, 1.6)
     li = np.zeros((8, 10), dtype=np.float32)
     li[0] = [0.01, 0.01, 0.01, 0.2, dim * 0.8, dim * 0.2, dim * 1.1, 0, 0, -1]
     ok = (c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c.add_to_settings_buffer("using_octree", "OCTENABLED", 0)
@@ -205,6 +208,17 @@ def test_device_dense_grid_builder_equals_the_host_emitter(depth, density, atlas
     assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
     with pytest.raises(vrc.VrcError):
         c.build_dense_grid(13, np.zeros(8, dtype=np.int8))
+    # the map's materials (mirrors among them) for the device-built tree: attachments from the array read back once
+    mats = rng.choice(np.array([5, 6, 1], dtype=np.int8), size=g.size, p=[0.7, 0.2, 0.1])
+    gm = np.where(g != 0, mats, 0).astype(np.int8)
+    tree = vrc.Octree(c.read_descriptors(), c.octree_size()[1], dim).attach_materials_from_grid(gm)
+    assert c.assign_octree_attachments(tree) and c.validate() and c.compute(), c.last_error()
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=li, atlas=atlas, tile_dim=(16, 16),
+                                    descriptors=host.descriptor_buffer, root_index=host.root_index, octree_dim=dim, using_octree=0,
+                                    max_distance=md, attachment_lookup=tree.attachment_lookup, attachments=tree.attachment_buffer)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+    if depth >= 6 and 0.01 <= float((g != 0).mean()) <= 0.3:
+        assert len(np.unique(c.read_hits()[..., 3])) >= 3           # several materials are in the picture
 
 
 def test_depth13_diamond_square_terrain_against_the_oracle(atlas):

@@ -495,6 +495,13 @@ class CLCaster:
                 _ptr(oct_.attachment_buffer, _u64p), oct_.attachment_buffer.size))
         return True
 
+    def assign_octree_attachments(self, octree: "Octree") -> bool:
+        """The two attachment arrays of `octree` (material per leaf voxel) for the tree that is already resident -- e.g. one
+        built on the device (build_dense_grid / build_heightfield) and read back once to compute them."""
+        return self._ok(lib.vrc_assign_octree_attachments(
+            self._h, _ptr(octree.attachment_lookup, C.POINTER(C.c_uint32)), octree.attachment_lookup.size,
+            _ptr(octree.attachment_buffer, _u64p), octree.attachment_buffer.size))
+
     def assign_octree_file(self, path: str) -> int:
         """Extension: stream a tree saved by Octree.Save straight into device memory; returns the map
         dimension stored in the file, 0 on failure."""
