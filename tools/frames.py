@@ -17,8 +17,14 @@ ap.add_argument("--hit-records", type=int, default=1)
 ap.add_argument("--set", action="append", default=[], help="name=value setting overrides")
 ap.add_argument("--streams", type=int, default=1, help="casters rendering concurrently (each its own HIP stream and buffers)")
 a = ap.parse_args()
-sc = bench.build_scene(a.depth)
-c = bench.make_caster(sc, a.width, a.height, 0, light_count=a.lights, hit_records=a.hit_records)
+if a.depth <= 13:
+    sc = bench.build_scene(a.depth)
+    c = bench.make_caster(sc, a.width, a.height, 0, light_count=a.lights, hit_records=a.hit_records)
+else:                                                   # deeper terrains only exist on the device (the host emitter would take hours)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from run_hist import device_caster
+    c = device_caster(a.depth, a.width, a.height)
+    assert c.add_to_settings_buffer("light_count", "LIGHT_COUNT", a.lights) and c.add_to_settings_buffer("hit_records", "HIT_RECORDS", a.hit_records)
 assert c.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", a.mode)
 for kv in a.set:
     k, v = kv.split("=")
