@@ -68,6 +68,16 @@ def test_soak_slice_device_builder_against_the_host_emitter():
     assert fields >= 10 and descriptors > 0 and bad == 0
 
 
+def test_soak_slice_array_kernel_against_svo_kernel_on_device_built_trees():
+    """Eight seconds of tests/soak_array_vs_svo_gpu.py with a fixed seed: random dense maps of 128^3 / 256^3 voxels with
+    materials and mirrors, the tree built on the device from the same grid (vrc_build_dense_grid + attachments), random
+    cameras inside the map: the array kernel's frame and the SVO kernel's frame (closed-form jumps forced on) are the
+    same image and the same hit records -- "SVO path == array path" beyond the sizes the oracle follows."""
+    import soak_array_vs_svo_gpu
+    bad, frames, maps = soak_array_vs_svo_gpu.run(budget=8.0, seed=20261002, depths=(7, 8))
+    assert maps >= 2 and frames >= 80 and bad == 0
+
+
 # ------------------------------------------------------------------ the array a reference host would pass
 @pytest.mark.parametrize("dim,density,seed", [(64, 0.5, 7), (128, 0.02, 5)], ids=["64^3-half-full", "128^3-sparse"])
 def test_strict_reference_buffer_through_both_branches(dim, density, seed, atlas):
