@@ -335,7 +335,9 @@ int vrc_octree_from_columns(uint32_t depth, const uint16_t *hi, const uint16_t *
  * PCIe once; occupancy pyramid, count, emit and validate run in the handle's HBM and the tree is installed as the octree
  * (materials: vrc_octree_attachments_from_grid on the array read back, or none).  3 <= depth <= 12 (4096^3 = 64 GiB).
  * Bit-identical to vrc_octree_generate_ex(grid, dim, VRC_LAYOUT_NO_PAGE_HEADERS).  validate_samples: tree point queries
- * against the grid, half of them on / next to solid voxels.                                                          */
+ * against the grid, half of them on / next to solid voxels.  grid == NULL: build from the map vrc_assign_map has already
+ * put into this handle's HBM (it must be dim^3) -- a host that uses both branches, like the reference's Application,
+ * uploads its Map once.                                                                                             */
 int vrc_build_dense_grid(vrc_caster *h, uint32_t depth, const int8_t *grid, uint32_t flags, uint64_t validate_samples,
                          vrc_build_info *info);
 /* Host twin: vrc_octree_generate with the layout flags of vrc_scene_shell_terrain_ex (array sized exactly). */

@@ -56,10 +56,12 @@ def run(budget=300.0, seed=1, depths=(7, 8, 9), w=320, h=200):
         for using_octree in (1, 0):                        # 1: the array kernel; 0: the SVO kernel (the reference's setting names)
             c = vrc.CLCaster()
             assert c.init(0)
-            info = c.build_dense_grid(depth, grid, validate_samples=1 << 16)
+            assert c.assign_map(grid, (dim, dim, dim))
+            # one caster builds the tree from the grid it is handed, the other from the map that is already in its HBM
+            info = c.build_dense_grid(depth, grid if using_octree else None, validate_samples=1 << 16)
             assert info["validate_mismatches"] == 0
             tree = vrc.Octree(c.read_descriptors(), c.octree_size()[1], dim).attach_materials_from_grid(grid)
-            ok = (c.assign_octree_attachments(tree) and c.assign_map(grid, (dim, dim, dim))
+            ok = (c.assign_octree_attachments(tree)
                   and c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c.add_to_settings_buffer("using_octree", "OCTENABLED", using_octree)
                   and c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", 3 * dim) and c.add_to_settings_buffer("light_count", "LIGHT_COUNT", 1)
                   and c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 16)

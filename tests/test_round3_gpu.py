@@ -199,6 +199,12 @@ def test_device_dense_grid_builder_equals_the_host_emitter(depth, density, atlas
         assert n == host.descriptor_buffer.size == info["n_descriptors"] and root == host.root_index
         assert np.array_equal(c.read_descriptors(), host.descriptor_buffer)
         assert c.build_dense_grid(depth, g, count_only=True)["n_descriptors"] == n
+        # the same tree from the map of the array branch, once that is resident (no second upload)
+        with pytest.raises(vrc.VrcError):
+            c.build_dense_grid(depth, None)
+        assert c.assign_map(g, (dim, dim, dim))
+        assert c.build_dense_grid(depth, None, validate_samples=1 << 16)["validate_mismatches"] == 0
+        assert np.array_equal(c.read_descriptors(), host.descriptor_buffer)
     # the last grid, rendered straight from the device-built tree
     w, h, md = 96, 64, 3 * dim
     g3 = g.reshape(dim, dim, dim)                                  # the camera sits in the empty voxel nearest to the centre

@@ -445,16 +445,18 @@ class CLCaster:
             raise VrcError(self.last_error())
         return info.as_dict()
 
-    def build_dense_grid(self, depth: int, grid: np.ndarray, count_only: bool = False, validate_samples: int = 0) -> dict:
+    def build_dense_grid(self, depth: int, grid: Optional[np.ndarray] = None, count_only: bool = False, validate_samples: int = 0) -> dict:
         """vrc_build_dense_grid: Octree::Generate's input (int8[dim^3], x + dim*(y + dim*z), non-zero = solid) built into the
-        SVO in HBM and installed as the octree.  Returns the build info; raises on failure."""
+        SVO in HBM and installed as the octree; grid None: from the map assign_map has already uploaded.  Returns the build
+        info; raises on failure."""
         dim = 1 << depth
-        grid = np.ascontiguousarray(grid, dtype=np.int8).reshape(-1)
-        if grid.size != dim ** 3:
-            raise VrcError("grid size does not match dim^3")
+        if grid is not None:
+            grid = np.ascontiguousarray(grid, dtype=np.int8).reshape(-1)
+            if grid.size != dim ** 3:
+                raise VrcError("grid size does not match dim^3")
         info = BuildInfo()
-        rc = lib.vrc_build_dense_grid(self._h, depth, _ptr(grid, _i8p), BUILD_COUNT_ONLY if count_only else 0, validate_samples,
-                                      C.byref(info))
+        rc = lib.vrc_build_dense_grid(self._h, depth, _ptr(grid, _i8p) if grid is not None else None,
+                                      BUILD_COUNT_ONLY if count_only else 0, validate_samples, C.byref(info))
         if not self._ok(rc):
             raise VrcError(self.last_error())
         return info.as_dict()

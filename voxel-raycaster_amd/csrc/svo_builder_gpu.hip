@@ -569,8 +569,9 @@ cleanup:
 // The same pipeline for Octree::Generate's own input (src/map/Octree.cpp:13-43: a dense grid, x + dim * (y + dim * z), any
 // non-zero voxel solid): the grid goes to the device once, an occupancy pyramid replaces the min / max pyramids, every
 // 64^3 brick that holds a voxel is a candidate.  On success *d_desc owns the array.
-int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_grid, uint32_t flags, uint64_t validate_samples,
-                      uint64_t **d_desc, vrc_build_info *out, std::string &error) {
+// resident_grid: the same grid already in this device's memory (the map of the array branch); then nothing is uploaded.
+int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_grid, const int8_t *resident_grid, uint32_t flags,
+                      uint64_t validate_samples, uint64_t **d_desc, vrc_build_info *out, std::string &error) {
     int rc = VRC_OK;
     vrc_build_info bi;
     memset(&bi, 0, sizeof(bi));
@@ -607,16 +608,19 @@ int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_gri
         size_t entries = 0;
         std::vector<size_t> off(depth + 1, 0);
         for (uint32_t l = 1; l <= depth; l++) { off[l] = entries; const size_t d = (size_t)(dim >> l); entries += d * d * d; }
-        GB_TRY(hipMalloc((void **)&d_grid, voxels));
+        if (!resident_grid) {
+            GB_TRY(hipMalloc((void **)&d_grid, voxels));
+            GB_TRY(hipMemcpyAsync(d_grid, host_grid, voxels, hipMemcpyHostToDevice, stream));
+            resident_grid = d_grid;
+        }
         GB_TRY(hipMalloc((void **)&d_occ, entries));
-        temp_bytes = voxels + entries;
-        GB_TRY(hipMemcpyAsync(d_grid, host_grid, voxels, hipMemcpyHostToDevice, stream));
-        src.occ[0] = (const uint8_t *)d_grid;
+        temp_bytes = (d_grid ? voxels : 0) + entries;
+        src.occ[0] = (const uint8_t *)resident_grid;
         for (uint32_t l = 1; l <= depth; l++) src.occ[l] = d_occ + off[l];
         {
             const int64_t d = dim >> 1;
             hipLaunchKernelGGL(occ1_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)d, (unsigned)d), dim3(256), 0, stream,
-                               (const int8_t *)d_grid, d_occ + off[1], dim);
+                               resident_grid, d_occ + off[1], dim);
         }
         for (uint32_t l = 2; l <= depth; l++) {
             const int64_t d = dim >> l;
@@ -700,7 +704,7 @@ int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_gri
             GB_TRY(hipMalloc((void **)&d_mis, sizeof(unsigned long long)));
             GB_TRY(hipMemsetAsync(d_mis, 0, sizeof(unsigned long long), stream));
             hipLaunchKernelGGL(validate_grid_kernel, dim3((unsigned)((validate_samples + 255) / 256)), dim3(256), 0, stream,
-                               (const int8_t *)d_grid, (int)depth, (const uint64_t *)desc, (uint64_t)0, validate_samples, (uint64_t)0x5eedULL, d_mis);
+                               resident_grid, (int)depth, (const uint64_t *)desc, (uint64_t)0, validate_samples, (uint64_t)0x5eedULL, d_mis);
             GB_TRY(hipGetLastError());
             unsigned long long mis = 0;
             GB_TRY(hipMemcpyAsync(&mis, d_mis, sizeof(mis), hipMemcpyDeviceToHost, stream));

@@ -37,8 +37,8 @@ int build_columns_device(hipStream_t stream, uint32_t depth, uint64_t seed, int3
                          const uint16_t *host_hi, const uint16_t *host_lo,
                          uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
                          int32_t *probe_lohi, uint64_t **d_desc, vrc_build_info *out, std::string &error);
-int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_grid, uint32_t flags, uint64_t validate_samples,
-                      uint64_t **d_desc, vrc_build_info *out, std::string &error);
+int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_grid, const int8_t *resident_grid, uint32_t flags,
+                      uint64_t validate_samples, uint64_t **d_desc, vrc_build_info *out, std::string &error);
 }  // namespace vrc
 
 struct vrc_setting { std::string name, define; int64_t value; };
@@ -681,8 +681,11 @@ int vrc_build_heightfield(vrc_caster *h, uint32_t depth, const uint16_t *hi, con
 
 int vrc_build_dense_grid(vrc_caster *h, uint32_t depth, const int8_t *grid, uint32_t flags, uint64_t validate_samples,
                          vrc_build_info *info) {
-    if (!h || depth < 3 || depth > 12 || !grid)
-        return fail(h, VRC_ERR_INVALID_ARGUMENT, "build_dense_grid: need 3 <= depth <= 12 and a grid");
+    if (!h || depth < 3 || depth > 12)
+        return fail(h, VRC_ERR_INVALID_ARGUMENT, "build_dense_grid: need 3 <= depth <= 12");
+    const int32_t dim = (int32_t)1 << depth;
+    if (!grid && !(h->d_map && h->map_dim[0] == dim && h->map_dim[1] == dim && h->map_dim[2] == dim))
+        return fail(h, VRC_ERR_INVALID_ARGUMENT, "build_dense_grid: no grid given and no %d^3 map assigned (vrc_assign_map) to build from", dim);
     HIP_TRY(h, hipSetDevice(h->device));
     const bool count_only = (flags & VRC_BUILD_COUNT_ONLY) != 0;
     if (!count_only) {
@@ -692,7 +695,7 @@ int vrc_build_dense_grid(vrc_caster *h, uint32_t depth, const int8_t *grid, uint
     uint64_t *d = nullptr;
     vrc_build_info bi;
     std::string err;
-    const int rc = vrc::build_grid_device(h->stream, depth, grid, flags, validate_samples, &d, &bi, err);
+    const int rc = vrc::build_grid_device(h->stream, depth, grid, grid ? nullptr : h->d_map, flags, validate_samples, &d, &bi, err);
     if (info) *info = bi;
     if (rc != VRC_OK) return fail(h, rc, "build_dense_grid: %s", err.c_str());
     if (count_only) return VRC_OK;
