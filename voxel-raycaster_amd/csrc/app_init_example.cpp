@@ -4,6 +4,7 @@
 // Writes the frame as raw float4 + hit records so a test can compare it with
 // the oracle.   usage: app_init_example <width> <height> <atlas.rgba> <out_prefix>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <memory>
 
@@ -56,6 +57,17 @@ int main(int argc, char **argv) {
     if (!raycaster->compute()) return 1;
     if (!raycaster->read_image(img)) return 1;
     f = std::fopen((p + ".image2.f32").c_str(), "wb"); std::fwrite(img.data(), 4, img.size(), f); std::fclose(f);
+    // extension: the octree generated on the device from the map that is already there (Octree::Generate without the host
+    // pass and without the 100 000-entry buffer): the frame does not change
+    if (!raycaster->generate_octree_from_assigned_map(*map) || !raycaster->validate() || !raycaster->compute()) {
+        std::fprintf(stderr, "device octree: %s\n", raycaster->last_error().c_str());
+        return 1;
+    }
+    std::vector<float> img3;
+    if (!raycaster->read_image(img3) || img3.size() != img.size() || std::memcmp(img3.data(), img.data(), img.size() * 4) != 0) {
+        std::fprintf(stderr, "the frame of the device-built octree differs\n");
+        return 1;
+    }
     std::printf("ok %dx%d\n", W, H);
     return 0;
 }
