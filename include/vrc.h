@@ -308,6 +308,7 @@ int vrc_scene_shell_column(uint32_t depth, uint64_t seed, int32_t thickness, int
  * that many pseudo-random voxels (tree point query vs the procedural occupancy).  probe_xy (n_probe x,y pairs) /
  * probe_lohi (n_probe lo,hi pairs): optional read-back of columns of the device height field.                      */
 #define VRC_BUILD_COUNT_ONLY 1u
+#define VRC_BUILD_ATTACHMENTS 2u   /* vrc_build_dense_grid: the grid's values become the tree's material attachments, on the device */
 typedef struct vrc_build_info {
     uint64_t n_descriptors, root_index;
     uint64_t n_bricks, n_top_slots, n_far_pointers_top;
@@ -333,7 +334,9 @@ int vrc_octree_from_columns(uint32_t depth, const uint16_t *hi, const uint16_t *
 /* The same builder for Octree::Generate's own input (src/map/Octree.cpp:13-43): a dense grid int8[dim^3],
  * x + dim*(y + dim*z), any non-zero voxel solid -- the reference's Map::data (src/map/Map.cpp:7-30).  The grid crosses
  * PCIe once; occupancy pyramid, count, emit and validate run in the handle's HBM and the tree is installed as the octree
- * (materials: vrc_octree_attachments_from_grid on the array read back, or none).  3 <= depth <= 12 (4096^3 = 64 GiB).
+ * (materials: flag VRC_BUILD_ATTACHMENTS turns the grid's values into the attachment arrays on the device -- one slot
+ * per non-empty 2^3 block in grid order -- so the SVO branch renders the map's materials, mirrors included; without
+ * the flag every voxel is material 5).  3 <= depth <= 12 (4096^3 = 64 GiB).
  * Bit-identical to vrc_octree_generate_ex(grid, dim, VRC_LAYOUT_NO_PAGE_HEADERS).  validate_samples: tree point queries
  * against the grid, half of them on / next to solid voxels.  grid == NULL: build from the map vrc_assign_map has already
  * put into this handle's HBM (it must be dim^3) -- a host that uses both branches, like the reference's Application,

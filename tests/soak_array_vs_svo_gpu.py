@@ -58,11 +58,14 @@ def run(budget=300.0, seed=1, depths=(7, 8, 9), w=320, h=200):
             assert c.init(0)
             assert c.assign_map(grid, (dim, dim, dim))
             # one caster builds the tree from the grid it is handed, the other from the map that is already in its HBM
-            info = c.build_dense_grid(depth, grid if using_octree else None, validate_samples=1 << 16)
+            # (and half of the maps get their material attachments from the device build, half from the host walk)
+            on_device = maps % 2 == 0
+            info = c.build_dense_grid(depth, grid if using_octree else None, validate_samples=1 << 16, attachments=on_device)
             assert info["validate_mismatches"] == 0
-            tree = vrc.Octree(c.read_descriptors(), c.octree_size()[1], dim).attach_materials_from_grid(grid)
-            ok = (c.assign_octree_attachments(tree)
-                  and c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c.add_to_settings_buffer("using_octree", "OCTENABLED", using_octree)
+            if not on_device:
+                tree = vrc.Octree(c.read_descriptors(), c.octree_size()[1], dim).attach_materials_from_grid(grid)
+                assert c.assign_octree_attachments(tree), c.last_error()
+            ok = (c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c.add_to_settings_buffer("using_octree", "OCTENABLED", using_octree)
                   and c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", 3 * dim) and c.add_to_settings_buffer("light_count", "LIGHT_COUNT", 1)
                   and c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 16)
                   and c.assign_camera(*cam) and c.create_viewport(w, h) and c.assign_lights(li) and c.create_texture_atlas(atlas, (16, 16))

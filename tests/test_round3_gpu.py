@@ -233,6 +233,17 @@ def test_device_dense_grid_builder_equals_the_host_emitter(depth, density, atlas
                                     descriptors=host.descriptor_buffer, root_index=host.root_index, octree_dim=dim, using_octree=0,
                                     max_distance=md, attachment_lookup=tree.attachment_lookup, attachments=tree.attachment_buffer)
     assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+    # ... and the same materials made on the device in the build itself (VRC_BUILD_ATTACHMENTS): the same frame
+    c2 = vrc.CLCaster()
+    assert c2.init(0)
+    info = c2.build_dense_grid(depth, gm, validate_samples=1 << 16, attachments=True)
+    assert info["validate_mismatches"] == 0 and np.array_equal(c2.read_descriptors(), host.descriptor_buffer)
+    ok = (c2.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c2.add_to_settings_buffer("using_octree", "OCTENABLED", 0)
+          and c2.add_to_settings_buffer("max_distance", "MAX_DISTANCE", md)
+          and c2.assign_camera(np.array(cam_dir, dtype=np.float32), np.array(cam_pos, dtype=np.float32)) and c2.create_viewport(w, h)
+          and c2.assign_lights(li) and c2.create_texture_atlas(atlas, (16, 16)) and c2.validate() and c2.compute())
+    assert ok, c2.last_error()
+    assert_same(c2.read_image(), c2.read_hits(), c2.counters(), oimg, ohits, octr)
     if depth >= 6 and 0.01 <= float((g != 0).mean()) <= 0.3:
         assert len(np.unique(c.read_hits()[..., 3])) >= 3           # several materials are in the picture
 

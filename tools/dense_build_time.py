@@ -21,8 +21,11 @@ for depth in [int(v) for v in sys.argv[1:]] or [8, 9, 10]:
     info = c.build_dense_grid(depth, g, validate_samples=1 << 22)
     t_dev = time.time() - t0
     same = np.array_equal(c.read_descriptors(), host.descriptor_buffer)
+    t0 = time.time()
+    c.build_dense_grid(depth, g, attachments=True)
+    t_att = time.time() - t0
     print(json.dumps({"grid": f"{dim}^3 ({g.nbytes / 2**20:.0f} MiB), 2 % noise over a solid slab", "descriptors": int(info["n_descriptors"]),
-                      "host_emitter_s": round(t_host, 3), "device_call_s": round(t_dev, 3),
+                      "host_emitter_s": round(t_host, 3), "device_call_s": round(t_dev, 3), "device_call_with_material_attachments_s": round(t_att, 3),
                       "device_phases_s": {"upload+pyramid": round(info["seconds_height"], 3), "count": round(info["seconds_count"], 3),
                                           "emit": round(info["seconds_emit"], 3)},
                       "validate_mismatches": int(info["validate_mismatches"]), "bit_identical_to_host": bool(same)}), flush=True)

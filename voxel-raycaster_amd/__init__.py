@@ -138,6 +138,7 @@ SIGNATURES = {
     "vrc_octree_size": (C.c_int, [_H, _u64p, _u64p]),
 }
 LAYOUT_STRICT_REFERENCE, LAYOUT_NO_PAGE_HEADERS, BUILD_COUNT_ONLY = 1, 2, 1
+BUILD_ATTACHMENTS = 2
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)
     _fn.restype = _res
@@ -445,7 +446,8 @@ class CLCaster:
             raise VrcError(self.last_error())
         return info.as_dict()
 
-    def build_dense_grid(self, depth: int, grid: Optional[np.ndarray] = None, count_only: bool = False, validate_samples: int = 0) -> dict:
+    def build_dense_grid(self, depth: int, grid: Optional[np.ndarray] = None, count_only: bool = False, validate_samples: int = 0,
+                         attachments: bool = False) -> dict:
         """vrc_build_dense_grid: Octree::Generate's input (int8[dim^3], x + dim*(y + dim*z), non-zero = solid) built into the
         SVO in HBM and installed as the octree; grid None: from the map assign_map has already uploaded.  Returns the build
         info; raises on failure."""
@@ -456,7 +458,8 @@ class CLCaster:
                 raise VrcError("grid size does not match dim^3")
         info = BuildInfo()
         rc = lib.vrc_build_dense_grid(self._h, depth, _ptr(grid, _i8p) if grid is not None else None,
-                                      BUILD_COUNT_ONLY if count_only else 0, validate_samples, C.byref(info))
+                                      (BUILD_COUNT_ONLY if count_only else 0) | (BUILD_ATTACHMENTS if attachments else 0),
+                                      validate_samples, C.byref(info))
         if not self._ok(rc):
             raise VrcError(self.last_error())
         return info.as_dict()

@@ -81,11 +81,12 @@ public:
         return ok(vrc_assign_octree(h_, m.descriptor_buffer, m.buffer_size, m.root_index));
     }
     // extension: Octree::Generate (src/map/Octree.cpp:13-43) on the device, from the map assign_map() has uploaded -- the
-    // host skips Map::regenerate and the descriptor upload (dimensions must be a power of two, 8..4096)
+    // host skips Map::regenerate and the descriptor upload, and the map's materials come along as attachments (dimensions
+    // must be a power of two, 8..4096)
     bool generate_octree_from_assigned_map(const Map &m) {
         uint32_t depth = 0;
         while ((1u << depth) < m.dimensions) depth++;
-        return (1u << depth) == m.dimensions && ok(vrc_build_dense_grid(h_, depth, nullptr, 0, 0, nullptr));
+        return (1u << depth) == m.dimensions && ok(vrc_build_dense_grid(h_, depth, nullptr, VRC_BUILD_ATTACHMENTS, 0, nullptr));
     }
     bool release_octree() { return ok(vrc_release_octree(h_)); }                                          // :119-131
     bool assign_camera(const Camera *camera) {                                                             // :133-143

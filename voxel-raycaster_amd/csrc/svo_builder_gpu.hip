@@ -299,6 +299,85 @@ __global__ void validate_grid_kernel(const int8_t *__restrict__ grid, int depth,
     if (found != expect) atomicAdd(mismatches, 1ULL);
 }
 
+// ---- materials of a dense grid as attachments (include/vrc.h, vrc_assign_octree_attachments): one 8-byte slot per
+// non-empty 2^3 block -- byte k = the grid's value at child k -- and lookup[index of the block's bottom-level descriptor] =
+// its slot.  Slots are numbered in grid order (x fastest), slot 0 is the default (all 5): three passes so that the
+// arrays are the same from run to run -- non-empty blocks per chunk of kAttachChunk, exclusive scan of the chunk counts,
+// and the fill, which finds each block's descriptor by walking the finished tree.
+constexpr int kAttachChunk = 4096;             // blocks per workgroup of 256 threads
+__global__ void attach_count_kernel(const uint8_t *__restrict__ occ1, uint64_t n_blocks, uint32_t *__restrict__ chunk_count) {
+    __shared__ uint32_t acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kAttachChunk;
+    uint32_t mine = 0;
+    for (int k = threadIdx.x; k < kAttachChunk; k += 256)
+        if (base + k < n_blocks && occ1[base + k]) mine++;
+    if (mine) atomicAdd(&acc, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_count[blockIdx.x] = acc;
+}
+// one workgroup: chunk_count -> exclusive prefix sums in place, the total in *total
+__global__ void attach_scan_kernel(uint32_t *chunk_count, uint64_t n_chunks, unsigned long long *total) {
+    __shared__ unsigned long long part[1024];
+    const uint64_t per = (n_chunks + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n_chunks ? lo + per : n_chunks;
+    unsigned long long sum = 0;
+    for (uint64_t i = lo; i < hi; i++) sum += chunk_count[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (uint64_t i = lo; i < hi; i++) { const uint32_t v = chunk_count[i]; chunk_count[i] = (uint32_t)run; run += v; }
+}
+// index of the bottom-level descriptor (node of 2^3 voxels) that holds voxel (x, y, z); the block is known to be non-empty
+__device__ __forceinline__ uint64_t tree_block_descriptor(const uint64_t *desc, uint64_t root_index, int depth, uint32_t x, uint32_t y, uint32_t z) {
+    uint64_t index = root_index, d = desc[index];
+    for (int l = depth - 1; l >= 1; l--) {
+        const uint32_t i = ((x >> l) & 1u) | (((y >> l) & 1u) << 1) | (((z >> l) & 1u) << 2);
+        const uint64_t at = index + (d & 0x7fffULL);
+        const uint64_t first = (d & kFarBit) ? desc[at] : at;
+        index = first + (uint64_t)(__popcll((d >> 16) & ((2ULL << i) - 1ULL)) - 1);
+        d = desc[index];
+    }
+    return index;
+}
+__global__ void attach_fill_kernel(const int8_t *__restrict__ grid, const uint8_t *__restrict__ occ1, int depth, const uint64_t *__restrict__ desc,
+                                   uint64_t root_index, const uint32_t *__restrict__ chunk_base, uint32_t *__restrict__ lookup,
+                                   uint64_t *__restrict__ attach) {
+    __shared__ uint32_t rank[256];
+    const int64_t dim = 1LL << depth, d = dim >> 1;
+    const uint64_t n_blocks = (uint64_t)d * d * d, base = (uint64_t)blockIdx.x * kAttachChunk;
+    constexpr int kPer = kAttachChunk / 256;                       // consecutive blocks per thread
+    const uint64_t first = base + (uint64_t)threadIdx.x * kPer;
+    uint32_t mine = 0;
+    for (int k = 0; k < kPer; k++) mine += (first + k < n_blocks && occ1[first + k]) ? 1u : 0u;
+    rank[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; i++) { const uint32_t v = rank[i]; rank[i] = run; run += v; }
+    }
+    __syncthreads();
+    uint32_t slot = 1u + chunk_base[blockIdx.x] + rank[threadIdx.x];
+    for (int k = 0; k < kPer; k++) {
+        const uint64_t b = first + k;
+        if (b >= n_blocks || !occ1[b]) continue;
+        const int64_t bx = (int64_t)(b % (uint64_t)d), by = (int64_t)((b / (uint64_t)d) % (uint64_t)d), bz = (int64_t)(b / (uint64_t)(d * d));
+        uint64_t packed = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            packed |= (uint64_t)(uint8_t)grid[(2 * bx + (c & 1)) + dim * ((2 * by + ((c >> 1) & 1)) + dim * (2 * bz + ((c >> 2) & 1)))] << (8 * c);
+        attach[slot] = packed;
+        lookup[tree_block_descriptor(desc, root_index, depth, (uint32_t)(2 * bx), (uint32_t)(2 * by), (uint32_t)(2 * bz))] = slot;
+        slot++;
+    }
+}
+
 // ---- the levels above the bricks, on the host (sequential, a few million nodes at most)
 struct TopNode { uint64_t desc = 0; int64_t k = -1; };
 
@@ -570,8 +649,11 @@ cleanup:
 // non-zero voxel solid): the grid goes to the device once, an occupancy pyramid replaces the min / max pyramids, every
 // 64^3 brick that holds a voxel is a candidate.  On success *d_desc owns the array.
 // resident_grid: the same grid already in this device's memory (the map of the array branch); then nothing is uploaded.
+// VRC_BUILD_ATTACHMENTS: the grid's values as material attachments, *d_lookup (uint32 per descriptor) and *d_attach
+// (*n_attach slots of 8 bytes), owned by the caller like *d_desc.
 int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_grid, const int8_t *resident_grid, uint32_t flags,
-                      uint64_t validate_samples, uint64_t **d_desc, vrc_build_info *out, std::string &error) {
+                      uint64_t validate_samples, uint64_t **d_desc, uint32_t **d_lookup, uint64_t **d_attach, uint64_t *n_attach,
+                      vrc_build_info *out, std::string &error) {
     int rc = VRC_OK;
     vrc_build_info bi;
     memset(&bi, 0, sizeof(bi));
@@ -587,7 +669,9 @@ int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_gri
     BrickRef *d_bricks = nullptr;
     BrickInfo *d_info = nullptr;
     uint64_t *d_bases = nullptr, *d_kv = nullptr, *desc = nullptr;
-    unsigned long long *d_mis = nullptr;
+    unsigned long long *d_mis = nullptr, *d_total = nullptr;
+    uint32_t *lookup = nullptr, *d_chunks = nullptr;
+    uint64_t *attach = nullptr;
     GridSrc src;
     memset(&src, 0, sizeof(src));
     src.depth = (int)depth;
@@ -601,6 +685,9 @@ int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_gri
     const double t0 = now_s();
     double t1 = t0, t2 = t0, t3 = t0;
     *d_desc = nullptr;
+    if (d_lookup) *d_lookup = nullptr;
+    if (d_attach) *d_attach = nullptr;
+    if (n_attach) *n_attach = 0;
 
     {
         // 1. the grid and its occupancy pyramid
@@ -700,6 +787,30 @@ int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_gri
         GB_TRY(hipStreamSynchronize(stream));
         t3 = now_s();
 
+        if ((flags & VRC_BUILD_ATTACHMENTS) && d_lookup && d_attach && n_attach) {
+            // 5. materials: one slot per non-empty 2^3 block, in grid order
+            const uint64_t half = (uint64_t)(dim >> 1), n_blocks = half * half * half, n_chunks = (n_blocks + kAttachChunk - 1) / kAttachChunk;
+            unsigned long long slots = 0;
+            GB_TRY(hipMalloc((void **)&d_chunks, n_chunks * sizeof(uint32_t)));
+            GB_TRY(hipMalloc((void **)&d_total, sizeof(unsigned long long)));
+            hipLaunchKernelGGL(attach_count_kernel, dim3((unsigned)n_chunks), dim3(256), 0, stream, src.occ[1], n_blocks, d_chunks);
+            hipLaunchKernelGGL(attach_scan_kernel, dim3(1), dim3(1024), 0, stream, d_chunks, n_chunks, d_total);
+            GB_TRY(hipGetLastError());
+            GB_TRY(hipMemcpyAsync(&slots, d_total, sizeof(slots), hipMemcpyDeviceToHost, stream));
+            GB_TRY(hipStreamSynchronize(stream));
+            if (slots + 1 > 0xffffffffULL) { error = "more than 2^32 attachment slots"; rc = VRC_ERR_LIMIT; goto cleanup; }
+            GB_TRY(hipMalloc((void **)&lookup, total * sizeof(uint32_t)));
+            GB_TRY(hipMalloc((void **)&attach, (slots + 1) * sizeof(uint64_t)));
+            temp_bytes += n_chunks * sizeof(uint32_t);
+            GB_TRY(hipMemsetAsync(lookup, 0, total * sizeof(uint32_t), stream));
+            GB_TRY(hipMemsetAsync(attach, 0x05, sizeof(uint64_t), stream));       // slot 0: the default material
+            hipLaunchKernelGGL(attach_fill_kernel, dim3((unsigned)n_chunks), dim3(256), 0, stream, resident_grid, src.occ[1], (int)depth,
+                               (const uint64_t *)desc, (uint64_t)0, (const uint32_t *)d_chunks, lookup, attach);
+            GB_TRY(hipGetLastError());
+            GB_TRY(hipStreamSynchronize(stream));
+            *n_attach = slots + 1;
+        }
+
         if (validate_samples) {
             GB_TRY(hipMalloc((void **)&d_mis, sizeof(unsigned long long)));
             GB_TRY(hipMemsetAsync(d_mis, 0, sizeof(unsigned long long), stream));
@@ -723,9 +834,11 @@ finish:
                     brick_index.size() * 4;
     *d_desc = desc;
     desc = nullptr;
+    if (lookup && attach) { *d_lookup = lookup; *d_attach = attach; lookup = nullptr; attach = nullptr; }
 
 cleanup:
     if (out) *out = bi;
+    (void)hipFree(lookup); (void)hipFree(attach); (void)hipFree(d_chunks); (void)hipFree(d_total);
     (void)hipFree(d_grid); (void)hipFree(d_occ); (void)hipFree(d_bricks); (void)hipFree(d_info); (void)hipFree(d_bases);
     (void)hipFree(d_kv); (void)hipFree(d_mis);
     if (desc) (void)hipFree(desc);

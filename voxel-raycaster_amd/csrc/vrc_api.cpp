@@ -38,7 +38,8 @@ int build_columns_device(hipStream_t stream, uint32_t depth, uint64_t seed, int3
                          uint32_t flags, uint64_t validate_samples, const int32_t *probe_xy, uint32_t n_probe,
                          int32_t *probe_lohi, uint64_t **d_desc, vrc_build_info *out, std::string &error);
 int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_grid, const int8_t *resident_grid, uint32_t flags,
-                      uint64_t validate_samples, uint64_t **d_desc, vrc_build_info *out, std::string &error);
+                      uint64_t validate_samples, uint64_t **d_desc, uint32_t **d_lookup, uint64_t **d_attach, uint64_t *n_attach,
+                      vrc_build_info *out, std::string &error);
 }  // namespace vrc
 
 struct vrc_setting { std::string name, define; int64_t value; };
@@ -695,11 +696,15 @@ int vrc_build_dense_grid(vrc_caster *h, uint32_t depth, const int8_t *grid, uint
     uint64_t *d = nullptr;
     vrc_build_info bi;
     std::string err;
-    const int rc = vrc::build_grid_device(h->stream, depth, grid, grid ? nullptr : h->d_map, flags, validate_samples, &d, &bi, err);
+    uint32_t *lookup = nullptr;
+    uint64_t *attach = nullptr, n_attach = 0;
+    const int rc = vrc::build_grid_device(h->stream, depth, grid, grid ? nullptr : h->d_map, flags, validate_samples, &d, &lookup, &attach,
+                                          &n_attach, &bi, err);
     if (info) *info = bi;
     if (rc != VRC_OK) return fail(h, rc, "build_dense_grid: %s", err.c_str());
     if (count_only) return VRC_OK;
     h->d_desc = d; h->n_desc = bi.n_descriptors; h->have_octree = true;
+    h->d_attach_lookup = lookup; h->d_attach = attach; h->n_attach = n_attach;
     const int rs = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)bi.root_index);
     if (rs != VRC_OK) return rs;
     return fan_out_tree(h);
