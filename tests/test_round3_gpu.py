@@ -248,6 +248,50 @@ def test_device_dense_grid_builder_equals_the_host_emitter(depth, density, atlas
         assert len(np.unique(c.read_hits()[..., 3])) >= 3           # several materials are in the picture
 
 
+@pytest.mark.parametrize("own_copies", [False, True], ids=["shared", "own-copies"])
+def test_dense_grid_build_on_a_group_handle(own_copies, atlas):
+    """vrc_build_dense_grid on rank 0 of a 3-rank group (all on this GPU; with own copies the ranks take the copy path of
+    ranks on other GPUs): the tree and its device-made material attachments reach every rank -- the gathered frame equals
+    the single handle's, mirrors included."""
+    import soak_array_vs_svo_gpu
+    depth, dim, w, h = 7, 128, 200, 136
+    grid = soak_array_vs_svo_gpu.make_map(np.random.default_rng(77), depth)
+    empty = np.argwhere(grid == 0)
+    z, y, x = empty[len(empty) // 2]
+    cam = (np.array([1.6, 0.9], dtype=np.float32), np.array([x + 0.4, y + 0.5, z + 0.3], dtype=np.float32))
+    views = [(1.6, 0.9), (1.6, 2.5), (1.6, 4.0), (1.6, 5.6), (0.4, 1.0), (2.7, 1.0)]      # the single handle keeps the busiest one
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:, 0:4] = 0.6
+    li[:, 4:7] = np.random.default_rng(78).random((8, 3)) * dim
+    frames = []
+    for ranks in (1, 3):
+        c = vrc.CLCaster()
+        assert c.init(0) if ranks == 1 else c.init_group([0] * ranks, band_rows=8, own_copies=own_copies)
+        assert c.assign_map(grid, (dim, dim, dim))
+        info = c.build_dense_grid(depth, None, validate_samples=1 << 16, attachments=True)
+        assert info["validate_mismatches"] == 0
+        ok = (c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c.add_to_settings_buffer("using_octree", "OCTENABLED", 0)
+              and c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", 3 * dim) and c.add_to_settings_buffer("light_count", "LIGHT_COUNT", 2)
+              and c.assign_camera(*cam) and c.create_viewport(w, h) and c.assign_lights(li) and c.create_texture_atlas(atlas, (16, 16))
+              and c.validate() and c.compute())
+        assert ok, c.last_error()
+        if ranks == 1:
+            seen = []
+            for v in views:
+                cam[0][:] = v
+                assert c.compute()
+                seen.append(len(np.unique(c.read_hits()[..., 3])))
+            cam[0][:] = views[int(np.argmax(seen))]
+            assert c.compute()
+        frames.append((c.read_image(), c.read_hits(), c.counters()))
+        if ranks == 3:
+            mem = [c.memory_usage(r) for r in range(3)]
+            assert [m["octree_shared"] for m in mem[1:]] == ([0, 0] if own_copies else [1, 1]), mem
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32)) and np.array_equal(frames[0][1], frames[1][1])
+    assert frames[0][2] == frames[1][2]
+    assert len(np.unique(frames[0][1][..., 3])) >= 3                # several materials in the picture
+
+
 def test_depth13_diamond_square_terrain_against_the_oracle(atlas):
     """f4 past the dense-grid limit: the 8192^2 diamond-square height field (67 M mt19937 draws on the host, in the
     reference's order) built into an SVO on the device -- no 8192^3 grid anywhere -- and rendered at 1080p; sampled rows
