@@ -95,3 +95,28 @@ def test_hand_laid_sparse_tree_encodes_the_same_octree_as_the_builder():
         d, r = treetools.sparse_octree(vox, depth)
         o = vrc.Octree.Generate(g.reshape(-1), dim, buffer_size=0, strict_reference=False)
         assert treetools.canonical(d, r, dim)[0] == treetools.canonical(o.descriptor_buffer, o.root_index, dim)[0]
+
+
+@pytest.mark.parametrize("dim,density", [(8, 0.3), (32, 0.05), (64, 0.5), (128, 0.002)])
+def test_dense_grid_layouts_encode_the_same_octree(dim, density):
+    """vrc_octree_generate_ex (the host twin of the device dense-grid builder): layout 0 is vrc_octree_generate's array,
+    layout VRC_LAYOUT_NO_PAGE_HEADERS holds the same tree -- every voxel of the grid answers the same point query
+    (Octree::GetVoxel, src/map/Octree.cpp:45-158) -- and empty / solid maps come out as the one-descriptor trees they are."""
+    rng = np.random.default_rng(dim)
+    g = (rng.random(dim ** 3) < density).astype(np.int8) * 5
+    paged = vrc.Octree.Generate(g, dim, strict_reference=False)
+    same = vrc.Octree.Generate(g, dim, layout=0)
+    brick = vrc.Octree.Generate(g, dim, layout=vrc.LAYOUT_NO_PAGE_HEADERS)
+    assert np.array_equal(paged.descriptor_buffer, same.descriptor_buffer) and paged.root_index == same.root_index
+    assert brick.descriptor_buffer.size <= paged.descriptor_buffer.size
+    g3 = g.reshape(dim, dim, dim)
+    pts = rng.integers(0, dim, (4000, 3)) if dim > 16 else np.argwhere(np.ones((dim, dim, dim), dtype=bool))
+    for z, y, x in pts:
+        want = bool(g3[z, y, x])
+        assert brick.GetVoxel((int(x), int(y), int(z)))[0] == want and paged.GetVoxel((int(x), int(y), int(z)))[0] == want
+    for fill in (0, 5):
+        t = vrc.Octree.Generate(np.full(dim ** 3, fill, dtype=np.int8), dim, layout=vrc.LAYOUT_NO_PAGE_HEADERS)
+        assert t.GetVoxel((dim // 2, 1, dim - 1))[0] == bool(fill)
+        if not fill:
+            assert t.descriptor_buffer.size == 1
+
