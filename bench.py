@@ -31,6 +31,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC: RCCL would fail with
+# hipIpcGetMemHandle: invalid argument); exported on the boxes already, set here for a launcher that drops the environment
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PREWARM_FRAMES = 40     # untimed frames rendered during set-up so that the GPU clocks have settled before the W warm-up steps
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
