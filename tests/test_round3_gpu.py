@@ -153,6 +153,29 @@ def test_exact_jumps_leave_the_frame_bit_identical(depth, lights, k):
         assert times[k] < times[1 << 24]
 
 
+def test_three_casters_in_flight_with_jumps_keep_their_frames():
+    """Three handles (three HIP streams, three jump-table buffers) rendering different sizes of the depth-12 scene at the
+    same time, frame after frame without a host sync in between, closed-form jumps on: every caster's frame stays the
+    frame it renders alone without jumps -- the kernels of different handles share CUs, L2s and XCDs, not tables."""
+    import bench
+    sc = bench.build_scene(12)
+    sizes = [(640, 360), (1920, 1080), (200, 136)]
+    casters, refs = [], []
+    for w, h in sizes:
+        c = bench.make_caster(sc, w, h, 0)
+        assert c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 1 << 24) and c.compute()
+        refs.append((c.read_image(), c.read_hits()))
+        assert c.overwrite_setting("jump_min_run", 96)
+        casters.append(c)
+    for _ in range(6):
+        for _ in range(5):
+            for c in casters:
+                assert c.compute_async(), c.last_error()
+        for c, (img, hits) in zip(casters, refs):
+            assert c.sync(), c.last_error()
+            assert np.array_equal(c.read_hits(), hits) and np.array_equal(c.read_image().view(np.uint32), img.view(np.uint32))
+
+
 # ------------------------------------------------------------------ device builder for any column scene (SURVEY 8f-4 at scale)
 @pytest.mark.parametrize("depth", [8, 9, 10])
 def test_device_heightfield_builder_equals_the_host_emitter(depth):
