@@ -12,10 +12,17 @@ nothing else, like the reference: setting hit_records = 0).  Prints ONE JSON lin
 
 N = 1: BASELINE.json configs[2] -- 4096^3 shell-terrain SVO (seed 1), 1920x1080, primary rays +
 one shadow ray per hit + Blinn-Phong + atlas, the reference's own ray table.
-N > 1 (weak scaling): the frame grows to 1920 x (1080*N) rows over the SAME field of view (vertical
+N > 1, --scaling weak (default): the frame grows to 1920 x (1080*N) rows over the SAME field of view (vertical
 supersampling xN, host-supplied ray table), row-tiled in interleaved 8-row bands, SVO replicated on
 every GPU, no data-path collective.  torch.distributed (RCCL) is used only for the barrier and the
 MAX/SUM reductions of the timing protocol.
+N > 1, --scaling strong: the frame stays W x H (the reference's own ray table) and its 8-row bands are dealt to the N ranks.
+
+The other BASELINE configs are one command each (they are parity-test cases, not the headline line):
+    configs[1]  python bench.py --depth 10 --shadow-rays 0
+    configs[3]  torchrun ... bench.py --gpus 8 --scaling strong --width 3840 --height 2160 --lights 2
+    configs[4]  torchrun ... bench.py --gpus 8 --scaling strong --depth 16 --thickness 33 --width 7680 --height 4320 --lights 4
+(depth >= 14: every rank builds the tree in its own HBM with the device builder, ~6 s for the 198 GB scene.)
 """
 from __future__ import annotations
 
@@ -74,6 +81,8 @@ def build_scene(depth: int, seed: int = 1):
             break
     if cz is None:
         cz = z0
+    # SURVEY 8d's camera as written: h(D/2, D/8) + D/16 + 0.29 (the reference's octree bias is NOT zero there)
+    survey_pos = np.array([cx + 0.37, cy + 0.41, int(height[cy, cx]) + dim // 16 + 0.29], dtype=np.float32)
     lights = np.zeros((8, 10), dtype=np.float32)
     lights[0] = [0.01, 0.01, 0.01, 0.2, dim / 4, dim / 4, 3 * dim / 4, -1.0, -1.0, -1.5]
     # lights 1-3: only the multi-light extension reads them (setting light_count; BASELINE configs[3]/[4] geometry)
@@ -82,8 +91,27 @@ def build_scene(depth: int, seed: int = 1):
     lights[3] = [0.01, 0.02, 0.01, 0.2, dim / 8 + 0.2, 5 * dim / 8 + 0.3, 7 * dim / 8 + 0.4, 0.0, 0.0, -1.0]
     return dict(depth=depth, dim=dim, octree=octree, height=height,
                 cam_pos=np.array([cx + 0.37, cy + 0.41, cz + 0.29], dtype=np.float32),
-                cam_dir=np.array([2.0, 1.5708], dtype=np.float32),
+                cam_dir=np.array([2.0, 1.5708], dtype=np.float32), survey_cam_pos=survey_pos,
+                camera_note=f"SURVEY 8d pose (D/2+0.37, D/8+0.41, h(D/2,D/8)+D/16+0.29) raised by {cz - int(survey_pos[2])} voxels to the first "
+                            "voxel whose get_oct_vox bias (ray_caster_kernel.cl:353-354) is zero: the reference-exact bias term stays "
+                            "active (octree_bias = 1) but adds nothing; survey_camera is the pose as written",
                 lights=lights, atlas=vrc.synthetic_atlas(256, 256))
+
+
+def device_scene_header(depth: int, thickness: int = 2):
+    """Scenes that only exist in HBM (depth >= 14; BASELINE configs[4] is depth 16, thickness 33: 24.7 G descriptors = 198 GB):
+    camera, lights and atlas by the same conventions; the tree itself is built by every rank on its own GPU (make_caster).
+    The camera is SURVEY 8d's as written (no host copy of the tree to search for a bias-free voxel), bias active."""
+    import voxel_raycaster_amd as vrc
+    dim = 1 << depth
+    _, hi = vrc.shell_column(depth, dim // 2, dim // 8, thickness=thickness)
+    small = build_scene(8)
+    lights = small["lights"].copy()
+    lights[:, 4:7] *= dim / 256.0
+    pos = np.array([dim / 2 + 0.37, dim / 8 + 0.41, hi + dim // 16 + 0.29], dtype=np.float32)
+    return dict(depth=depth, dim=dim, octree=None, device_built=True, thickness=thickness, cam_pos=pos, survey_cam_pos=pos,
+                cam_dir=np.array([2.0, 1.5708], dtype=np.float32), lights=lights, atlas=small["atlas"],
+                camera_note="SURVEY 8d pose as written, the reference's octree bias active (octree_bias = 1)")
 
 
 def supersampled_table(width: int, height: int, n: int) -> np.ndarray:
@@ -102,6 +130,17 @@ def supersampled_table(width: int, height: int, n: int) -> np.ndarray:
     return t
 
 
+def _scene_tree(c, sc, octree_file):
+    """The SVO into this caster's HBM: uploaded from the host array, streamed from rank 0's file, or built on the device."""
+    if sc.get("device_built"):
+        info, _ = c.build_shell_terrain(sc["depth"], 1, sc["thickness"], 2)
+        sc["n_desc"] = int(info["n_descriptors"])
+        return True
+    if octree_file is not None:
+        return c.assign_octree_file(octree_file) == sc["dim"]
+    return c.assign_octree(sc["octree"])
+
+
 def make_caster(sc, width, height, device, table=None, shadow_rays=1, light_count=1, row_slice=None, octree_file=None,
                 hit_records=1):
     import voxel_raycaster_amd as vrc
@@ -116,7 +155,7 @@ def make_caster(sc, width, height, device, table=None, shadow_rays=1, light_coun
           and c.add_to_settings_buffer("shadow_rays", "SHADOW_RAYS", shadow_rays)
           and c.add_to_settings_buffer("light_count", "LIGHT_COUNT", light_count)
           and c.add_to_settings_buffer("hit_records", "HIT_RECORDS", hit_records)
-          and (c.assign_octree(sc["octree"]) if octree_file is None else c.assign_octree_file(octree_file) == sc["dim"])
+          and _scene_tree(c, sc, octree_file)
           and c.assign_camera(sc["cam_dir"], sc["cam_pos"])
           and (c.create_viewport(width, height) if table is None else c.create_viewport_table(table))
           and c.assign_lights(sc["lights"])
@@ -171,7 +210,7 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(sc, width, height, gpu_frame=None):
+def cpu_baseline(sc, width, height, gpu_frame=None, shadow_rays=1, lights=1):
     """The CPU oracle ("port" of the kernel: DDA + atlas + Blinn-Phong + shadow) timed on ALL host cores
     (OpenMP over rows) on the same frame.  The sample is bounded: the whole frame when the host has enough
     cores to finish ~170 core-seconds of work in seconds, otherwise every k-th row.  Since the oracle frame
@@ -190,7 +229,7 @@ def cpu_baseline(sc, width, height, gpu_frame=None):
                                   lights=sc["lights"], atlas=sc["atlas"], tile_dim=(16, 16),
                                   descriptors=sc["octree"].descriptor_buffer, root_index=sc["octree"].root_index,
                                   octree_dim=sc["dim"], using_octree=0, max_distance=3 * sc["dim"],
-                                  rows=(y, y1), threads=cores, want_hits=False)
+                                  rows=(y, y1), threads=cores, want_hits=False, shadow_rays=shadow_rays, active_lights=lights)
         secs += time.perf_counter() - t0
         rays += ctr["primary_rays"] + ctr["shadow_rays"]
         rows_done += y1 - y
@@ -214,19 +253,24 @@ def ray_cpp_baseline():
             "workload": "configs[0]: 256^3 dense grid, 640x480, Ray::Cast restated (600-step cap)", "dda_steps": steps}
 
 
-def shared_scene(depth, rank, world, tag, dist_on=False):
+def shared_scene(depth, rank, world, tag, dist_on=False, thickness=2):
     """The scene is built ONCE: rank 0 builds it and saves the tree (vrc_octree_save); the other ranks stream the file
     straight into their own HBM (vrc_assign_octree_file) and never hold a host copy.  Returns (scene dict, file or None)."""
     import torch.distributed as dist
     import voxel_raycaster_amd as vrc
+    if depth >= 14:
+        return device_scene_header(depth, thickness), None
     if not dist_on:
-        return build_scene(depth), None
+        sc = build_scene(depth) if thickness == 2 else None
+        if sc is None:
+            raise SystemExit("--thickness other than 2 needs the device builder (--depth >= 14)")
+        return sc, None
     path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"vrc_bench_{tag}.svo")
     meta = [None]
     if rank == 0:
         sc = build_scene(depth)
         sc["octree"].Save(path)
-        meta[0] = {k: sc[k] for k in ("depth", "dim", "cam_pos", "cam_dir", "lights")}
+        meta[0] = {k: sc[k] for k in ("depth", "dim", "cam_pos", "cam_dir", "lights", "survey_cam_pos", "camera_note")}
         meta[0]["n_desc"] = int(sc["octree"].descriptor_buffer.size)
     dist.broadcast_object_list(meta, src=0)
     if rank != 0:
@@ -243,6 +287,11 @@ def main():
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--lights", type=int, default=1, help="setting light_count (multi-light extension; BASELINE configs[3]: 2, configs[4]: 4)")
+    ap.add_argument("--shadow-rays", type=int, default=1, choices=(0, 1), help="0: primary rays only (BASELINE configs[1])")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = the frame grows to H*N rows over the same field of view; strong = the W x H frame is row-tiled over the N ranks")
+    ap.add_argument("--thickness", type=int, default=2, help="shell thickness of the terrain (device-built scenes, depth >= 14; configs[4]: 33)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-build", action="store_true",
                     help="never spawn a compiler: fail if a library is stale (required under rocprofv3: the profiler's preloaded "
@@ -289,22 +338,23 @@ def main():
         barrier(local_rank)                # rank 0's build is finished before any other rank imports the library
     import voxel_raycaster_amd  # noqa: F401  (fails loudly if the HIP library is missing)
 
-    sc, tree_file = shared_scene(args.depth, rank, world, os.environ.get("MASTER_PORT", "0"), dist_on)
+    sc, tree_file = shared_scene(args.depth, rank, world, os.environ.get("MASTER_PORT", "0"), dist_on, args.thickness)
     if tree_file and rank == 0:                                # /dev/shm is memory: the file must not outlive a failed run
         import atexit
         atexit.register(lambda: os.path.exists(tree_file) and os.remove(tree_file))
     W, H = args.width, args.height
-    full_h = H * world
-    table = None if world == 1 else supersampled_table(W, H, world)
+    strong = args.scaling == "strong" or world == 1
+    full_h = H if strong else H * world
+    table = None if strong else supersampled_table(W, H, world)
     # N > 1: each rank holds only its row bands of the ray table / frame / hit records (1/N of the frame)
     # the timed frame is the production frame: like the reference it writes the image and nothing else (the 8 x int32 hit
     # record per pixel exists for the parity tests; the same frame with records on is reported as `with_hit_records`)
     c = make_caster(sc, W, full_h, local_rank, table=table, row_slice=None if world == 1 else (rank, world, 8),
-                    octree_file=None if rank == 0 else tree_file, hit_records=0)
+                    octree_file=None if rank == 0 else tree_file, hit_records=0, shadow_rays=args.shadow_rays, light_count=args.lights)
     del table
     if dist_on:
         barrier(local_rank)
-        if rank == 0 and os.path.exists(tree_file):
+        if rank == 0 and tree_file and os.path.exists(tree_file):
             os.remove(tree_file)
 
     # what a caller sees without any pre-warming: the first `steps` frames of this fresh process (clocks still ramping),
@@ -358,12 +408,21 @@ def main():
         # HBM bytes and VALU instructions per launch come from rocprofv3 PMC passes (tools/gpu_profile.sh: counters cannot be
         # read inside this process).  The committed measurement is stamped with the hash of the kernel sources it was
         # taken on; a different kernel => null, never a stale number.
-        traffic, issue, pmc_note = None, None, "no PMC measurement for this workload"
-        if world == 1 and args.depth == 12 and (W, H) == (1920, 1080) and args.pmc_traffic and os.path.exists(args.pmc_traffic):
+        traffic, issue, pmc_note, traffic_split = None, None, "no PMC measurement for this workload", None
+        headline = (args.depth, W, H, args.lights, args.shadow_rays, args.thickness) == (12, 1920, 1080, 1, 1, 2)
+        if world == 1 and headline and args.pmc_traffic and os.path.exists(args.pmc_traffic):
             pmc = json.load(open(args.pmc_traffic))
             if pmc.get("kernel_source_hash") == kernel_source_hash():
                 traffic = pmc.get("hbm_bytes_per_launch")
                 pmc_note = pmc.get("source")
+                # what the one `traffic` number is made of: reads (FETCH_SIZE, doubled per the guide's gfx950 correction), writes
+                # (WRITE_SIZE), and the part of the writes that is the frame itself -- the rest of the writes is scratch and the
+                # jump tables' rows written through
+                if pmc.get("fetch_size_kib_raw") is not None:
+                    traffic_split = {"fetch_bytes": int(2 * pmc["fetch_size_kib_raw"] * 1024), "write_bytes": int(pmc["write_size_kib_raw"] * 1024),
+                                     "frame_bytes": int(16 * written),
+                                     "write_over_frame": round(pmc["write_size_kib_raw"] * 1024 / max(16 * written, 1), 2),
+                                     "algorithmic_descriptor_bytes": int(8 * ctr["descriptor_reads"])}
                 valu = pmc.get("valu_insts_per_launch")
                 if valu:
                     # the float recurrence of ray_caster_kernel.cl:558-559 (min, three masks, three fused updates = 10 wave64
@@ -375,26 +434,43 @@ def main():
                              "valu_over_stepping_floor": round(valu / floor, 4),
                              "achieved_ginst_s": round(rate, 1), "peak_ginst_s": VALU_PEAK_GINST_S,
                              "frac": round(rate / VALU_PEAK_GINST_S, 4),
-                             "note": "instruction count, not issue time: fp64 / reciprocal / 32-bit multiply instructions of the jump block take 2-4 issue slots"}
+                             "note": "frac counts instructions; frac_time_weighted weighs every instruction class with its measured issue interval"}
+                    tw = pmc.get("valu_time_weighted")
+                    if tw:
+                        # share of the launch's SIMD cycles in which a VALU instruction is being issued: per-class counts
+                        # (SQ_INSTS_VALU_<class>) x the issue interval tools/ubench/valu_issue.hip measures for the class
+                        issue.update({"frac_time_weighted": tw["frac_time_weighted"], "frac_time_weighted_range": tw["frac_time_weighted_range"],
+                                      "issue_cycles_per_launch": int(tw["issue_cycles_mid"]), "simd_cycles_per_launch": int(tw["simd_cycles_per_launch"]),
+                                      "classes": tw["classes"], "time_weighted_source": tw["source"]})
             else:
                 pmc_note = "profiles/traffic_latest.json was measured on other kernel sources: re-run tools/gpu_profile.sh + tools/update_profiles.py"
+        n_desc = int(sc["octree"].descriptor_buffer.size) if sc.get("octree") is not None else int(sc.get("n_desc", 0))
+        rehearsal_note = ("ranks share GPU 0 over gloo (VRC_BENCH_REHEARSAL): a rehearsal of the N > 1 code path, not a scaling measurement"
+                          if rehearsal else None)
         out = {
-            "metric": "Mrays/s (primary+shadow), 1920x1080 into depth-12 SVO",
+            "metric": metric_name(args, W, H),
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(max_dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(max_dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak" if (world == 1 or not strong) else "strong",
             "value_no_prewarm": round(value_no_prewarm, 3) if world == 1 else None,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: {sc['dim']}^3 (depth-{args.depth}) shell-terrain SVO seed 1, "
-                                   f"{W}x{H}{'' if world == 1 else f' x{world} rows (vertical supersampling)'}, "
-                                   "primary + 1-light shadow + Blinn-Phong + texture atlas, max_distance 3*dim",
-                       "descriptors": int(sc["octree"].descriptor_buffer.size),
+            "config": {"workload": workload_name(args, sc, W, H, world, strong),
+                       "descriptors": n_desc,
                        "rays_per_step": int(total_rays), "parallelism": f"row-slices x{world}, SVO replicated",
-                       "stepping": "exact per-voxel DDA (bit-identical to the reference array branch); long empty runs in closed form "
-                                   "(exact_jump.hpp: same float sequence and iteration count), setting jump_min_run",
+                       "camera": {"position": [float(v) for v in sc["cam_pos"]], "direction_inclination_azimuth": [float(v) for v in sc["cam_dir"]],
+                                  "octree_bias": 1, "note": sc.get("camera_note", "")},
+                       "lights": args.lights, "shadow_rays": args.shadow_rays,
+                       "stepping": "exact per-voxel DDA, bit-identical to the oracle (oracle/vrc_oracle.c); oracle vs the reference's own gfx950 "
+                                   "build of kernels/ray_caster_kernel.cl: integer decisions (hit voxel, face, material, step counts) equal, RGB within "
+                                   "1e-5 relative on 99.99 % of shaded pixels (the OpenCL library's 1-2 ulp normalize, DESIGN.md 2).  Long empty runs in "
+                                   "closed form (exact_jump.hpp: same float sequence and iteration count), setting jump_min_run",
                        "prewarm_frames": PREWARM_FRAMES,
-                       "frame": "production frame: image only, like the reference (hit_records = 0); with_hit_records is the same frame plus the parity records"},
+                       "frame": "production frame: image only, like the reference (hit_records = 0); with_hit_records is the same frame plus the parity records",
+                       "multi_gpu": ("no N > 1 hardware measurement is recorded in this repository (SCALE_r01..r03 were skipped: no 8-GPU node); "
+                                     "an N > 1 line is only a measurement when the driver launched it on N distinct GPUs"
+                                     + ("; THIS line: " + rehearsal_note if rehearsal_note else ""))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_split": traffic_split,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel": "raycast_svo_kernel",
                          "binding_roof": "valu_issue",
@@ -403,7 +479,9 @@ def main():
                          "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"], "valu_issue": issue,
                          "pmc_source": pmc_note, "kernel_source_hash": kernel_source_hash()},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not sc.get("device_built"):
+            out["survey_camera"] = survey_camera_leg(sc, c, args)
+        if world == 1 and not args.no_cpu_baseline and not sc.get("device_built"):
             out.update(supplementary(sc, c, W, H, local_rank, args, rays_per_step))
         if dist_on and world == 1:
             out["config"]["distributed_path"] = f"forced on a world of one ({dist.get_backend()}): barrier, broadcast_object_list, all_reduce executed"
@@ -411,6 +489,53 @@ def main():
     if dist_on:
         barrier(local_rank)
         dist.destroy_process_group()
+
+
+def metric_name(args, W, H):
+    if (args.depth, W, H) == (12, 1920, 1080):
+        return "Mrays/s (primary+shadow), 1920x1080 into depth-12 SVO"
+    return f"Mrays/s ({'primary+shadow' if args.shadow_rays else 'primary only'}), {W}x{H} into depth-{args.depth} SVO"
+
+
+def workload_name(args, sc, W, H, world, strong):
+    """Names the BASELINE.json config the command line selects (the headline line is configs[2])."""
+    key = (args.depth, W, H, args.lights, args.shadow_rays)
+    which = {(10, 1920, 1080, 1, 0): "BASELINE configs[1]", (12, 1920, 1080, 1, 1): "BASELINE configs[2]",
+             (12, 3840, 2160, 2, 1): "BASELINE configs[3]", (16, 7680, 4320, 4, 1): "BASELINE configs[4]"}.get(key, "other")
+    if which == "BASELINE configs[4]" and args.thickness != 33:
+        which = "BASELINE configs[4] geometry (thin shell: not the ~200 GB tree; --thickness 33 is)"
+    rows = "" if world == 1 else (f", row-tiled over {world} ranks (strong scaling)" if strong else f" x{world} rows (vertical supersampling, weak scaling)")
+    shading = ("primary + shadow rays toward " + (f"{args.lights} lights" if args.lights > 1 else "1 light") if args.shadow_rays else "primary rays only")
+    built = f", built on the device (thickness {sc['thickness']})" if sc.get("device_built") else ""
+    return (f"{which}: {sc['dim']}^3 (depth-{args.depth}) shell-terrain SVO seed 1{built}, {W}x{H}{rows}, {shading} + Blinn-Phong + texture atlas, "
+            "max_distance 3*dim")
+
+
+def survey_camera_leg(sc, c, args):
+    """The same frame from SURVEY 8d's camera AS WRITTEN, measured in the same run: there the reference's octree bias
+    (ray_caster_kernel.cl:353-354) is not zero and shears the rays (parity at this pose: tests/test_round2_gpu.py
+    test_headline_size_frame_with_the_reference_bias_active).  `value` stays on the bias-free pose config.camera describes."""
+    import torch
+    pos = np.ascontiguousarray(sc["survey_cam_pos"], dtype=np.float32)
+    assert c.assign_camera(sc["cam_dir"], pos), c.last_error()
+    try:
+        for _ in range(5):
+            assert c.compute(), c.last_error()
+        ctr = c.counters()
+        rays = ctr["primary_rays"] + ctr["shadow_rays"]
+        c.timing_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            assert c.compute(), c.last_error()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        nl, ms = c.timing()
+    finally:
+        assert c.assign_camera(sc["cam_dir"], sc["cam_pos"]), c.last_error()
+    return {"ms_per_step": round(dt / args.steps * 1e3, 4), "value": round(rays * args.steps / dt / 1e6, 3), "unit": "Mrays/s",
+            "kernel_ms_avg": round(ms / max(nl, 1), 4), "rays_per_step": int(rays), "steps": ctr["steps"], "descriptor_reads": ctr["descriptor_reads"],
+            "camera": {"position": [float(v) for v in pos], "octree_bias": 1, "note": "SURVEY 8d pose as written; the reference's bias term is non-zero here"}}
 
 
 def supplementary(sc, c, W, H, device, args, rays_per_step):
@@ -430,7 +555,7 @@ def supplementary(sc, c, W, H, device, args, rays_per_step):
     # two frames in flight (a second caster = second HIP stream + its own buffers) hide the kernel's ramp-up and tail;
     # the headline `value` is one frame at a time, like CLCaster::compute
     assert c.overwrite_setting("hit_records", 0)
-    c2 = make_caster(sc, W, H, device, hit_records=0)
+    c2 = make_caster(sc, W, H, device, hit_records=0, shadow_rays=args.shadow_rays, light_count=args.lights)
     for _ in range(2):
         assert c2.compute(), c2.last_error()
     torch.cuda.synchronize()
@@ -450,7 +575,7 @@ def supplementary(sc, c, W, H, device, args, rays_per_step):
     except Exception as e:                     # the supplementary mode must never take the headline line down
         out["mode_b_node_exit_jumps"] = {"error": str(e)}
     assert c.overwrite_setting("hit_records", 0)
-    rays, secs, used, cores, nrows, same = cpu_baseline(sc, W, H, gpu_frame=gpu_frame)
+    rays, secs, used, cores, nrows, same = cpu_baseline(sc, W, H, gpu_frame=gpu_frame, shadow_rays=args.shadow_rays, lights=args.lights)
     out["cpu_baseline"] = {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": used, "kind": "port",
                            "sample": f"{nrows} of {H} rows of the same frame, oracle/vrc_oracle.c (scalar C, OpenMP over pixels), "
                                      f"{used} of {cores} host threads; {rays} rays in {secs:.2f} s",

@@ -287,6 +287,9 @@ int vrc_scene_shell_terrain_dense(uint32_t depth, uint64_t seed, int32_t thickne
  * below the height of each column, 0 above (our definition; the reference has none).  dim <= 4096 with a grid,
  * <= 16384 without (then feed the heights to vrc_build_heightfield: no dense grid anywhere).                    */
 int vrc_scene_diamond_square(uint32_t dim, double corner_seed, uint8_t *height, int8_t *grid);
+/* The same field before Map.cpp:248 quantises it: double[dim*dim], x + dim*y (what `height_map` holds at :244).  For
+ * checks against a second implementation (oracle/diamond_square.py): the uint8 heights hide everything below one voxel. */
+int vrc_scene_diamond_square_f64(uint32_t dim, double corner_seed, double *field);
 
 /* The same scene with its knobs exposed: octave_floor = log2 of the finest noise cell (2 in vrc_scene_shell_terrain),
  * layout = VRC_LAYOUT_* flags.  VRC_LAYOUT_NO_PAGE_HEADERS is the "brick" layout the device builder emits: same

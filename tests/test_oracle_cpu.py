@@ -144,6 +144,29 @@ def test_diamond_square_heightmap_scene():
     assert orc.octree_validate(g1, 64, buf, root) == 0
 
 
+def test_diamond_square_second_implementation_and_golden_heights():
+    """f4 against a SECOND implementation (oracle/diamond_square.py: its own Mersenne Twister, generate_canonical and loop
+    nest, no code shared with vrc_scene_diamond_square): the double field of Map.cpp:144-244 bit for bit at 64^2 ... 1024^2,
+    the uint8 heights of :248, and the committed 64^2 vector.  Known answers that pin the random sequence itself: the C++
+    standard requires the 10000th output of a default-constructed std::mt19937 to be 4123659995; glibc's first rand() of
+    an unseeded process is 1804289383, so Map.cpp:160's corner seed is 58."""
+    from oracle import diamond_square as ds
+    assert int(ds.MT19937().words(10000)[-1]) == 4123659995
+    assert 1804289383 % 10 + 55 == 58
+    for dim in (64, 128, 256, 512, 1024):
+        want = ds.height_field(dim)
+        got = vrc.diamond_square_field(dim)
+        assert np.array_equal(want.view(np.uint64), got.view(np.uint64)), f"{dim}: double fields differ"
+        h, _ = vrc.diamond_square(dim, want_grid=False)
+        assert np.array_equal(h, ds.height_bytes(dim))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "diamond_square_64.npz"))
+    assert np.array_equal(vrc.diamond_square_field(64).view(np.uint64), g["field"].view(np.uint64))
+    assert np.array_equal(vrc.diamond_square(64, want_grid=False)[0], g["height"])
+    assert np.array_equal(ds.height_field(64).view(np.uint64), g["field"].view(np.uint64))
+    # another corner seed reaches both the same way
+    assert np.array_equal(ds.height_field(128, 61.0).view(np.uint64), vrc.diamond_square_field(128, 61.0).view(np.uint64))
+
+
 def test_octree_save_load_roundtrip(tmp_path):
     rng = np.random.default_rng(21)
     g = (rng.random(32 ** 3) < 0.1).astype(np.int8) * 5

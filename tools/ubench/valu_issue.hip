@@ -47,10 +47,24 @@ __global__ __launch_bounds__(256) void k_##name(float *out, unsigned long long *
 #define OP_MADU(i)   "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
 #define OP_BFE(i)    "v_bfe_u32 %" #i ", %" #i ", 3, 5\n"
 #define OP_SUB(i)    "v_sub_f32 %" #i ", %" #i ", %9\n"
+#define OP_SQRT(i)   "v_sqrt_f32 %" #i ", %" #i "\n"
+#define OP_FLOOR(i)  "v_floor_f32 %" #i ", %" #i "\n"
+#define OP_RNDNE(i)  "v_rndne_f32 %" #i ", %" #i "\n"
+#define OP_CVTF(i)   "v_cvt_f32_i32 %" #i ", %" #i "\n"
+#define OP_MULLO(i)  "v_mul_lo_u32 %" #i ", %" #i ", %9\n"
+#define OP_MULHI(i)  "v_mul_hi_u32 %" #i ", %" #i ", %9\n"
+#define OP_MUL24(i)  "v_mul_u32_u24 %" #i ", %" #i ", %9\n"
+#define OP_SUBU(i)   "v_sub_u32 %" #i ", %" #i ", %9\n"
+#define OP_CMPU(i)   "v_cmp_lt_u32 vcc, %" #i ", %9\n"
+#define OP_CNDV(i)   "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define OP_FFBH(i)   "v_ffbh_u32 %" #i ", %" #i "\n"
+#define OP_BCNT(i)   "v_bcnt_u32_b32 %" #i ", %" #i ", %9\n"
 
 DEFK(fma, OP_FMA) DEFK(add, OP_ADD) DEFK(mul, OP_MUL) DEFK(fmac, OP_FMAC) DEFK(fmaclamp, OP_FMACL) DEFK(minf, OP_MIN)
 DEFK(min3, OP_MIN3) DEFK(maxf, OP_MAX) DEFK(cmp, OP_CMP) DEFK(cnds, OP_CNDS) DEFK(cvt, OP_CVT) DEFK(addu, OP_ADDU)
 DEFK(andb, OP_AND) DEFK(lshl, OP_LSHL) DEFK(mov, OP_MOV) DEFK(rcp, OP_RCP) DEFK(madu, OP_MADU) DEFK(bfe, OP_BFE) DEFK(sub, OP_SUB)
+DEFK(sqrtf, OP_SQRT) DEFK(floorf, OP_FLOOR) DEFK(rndne, OP_RNDNE) DEFK(cvtf, OP_CVTF) DEFK(mullo, OP_MULLO) DEFK(mulhi, OP_MULHI)
+DEFK(mul24, OP_MUL24) DEFK(subu, OP_SUBU) DEFK(cmpu, OP_CMPU) DEFK(cndv, OP_CNDV) DEFK(ffbh, OP_FFBH) DEFK(bcnt, OP_BCNT)
 
 // packed f32 (two f32 operations per lane and instruction, 64-bit register pairs)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -74,6 +88,40 @@ __global__ __launch_bounds__(256) void k_##name(float *out, unsigned long long *
 #define OP_PKMUL(i)   "v_pk_mul_f32 %" #i ", %" #i ", %8\n"
 DEFK2(pkfma, OP_PKFMA) DEFK2(pkfmacl, OP_PKFMACL) DEFK2(pkadd, OP_PKADD) DEFK2(pkmul, OP_PKMUL)
 
+// fp64 (64-bit register pairs): the closed-form jumps' modular products, floors and reciprocal refinements (exact_jump.hpp)
+#define DEFK3(name, OP)                                                                                    \
+__global__ __launch_bounds__(256) void k_##name(float *out, unsigned long long *cyc, int iters) {          \
+    double r0 = threadIdx.x + 1.0, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7; \
+    double k0 = 1.0001, k1 = 0.5;                                                                           \
+    const unsigned long long t0 = __builtin_readcyclecounter();                                             \
+    for (int i = 0; i < iters; i++) { BODY2(OP) }                                                           \
+    const unsigned long long t1 = __builtin_readcyclecounter();                                             \
+    out[blockIdx.x * 256 + threadIdx.x] = (float)(r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7);                   \
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                       \
+}
+#define OP_FMA64(i)   "v_fma_f64 %" #i ", %" #i ", %8, %9\n"
+#define OP_MUL64(i)   "v_mul_f64 %" #i ", %" #i ", %8\n"
+#define OP_ADD64(i)   "v_add_f64 %" #i ", %" #i ", %9\n"
+#define OP_FLOOR64(i) "v_floor_f64 %" #i ", %" #i "\n"
+#define OP_FRACT64(i) "v_fract_f64 %" #i ", %" #i "\n"
+DEFK3(fma64, OP_FMA64) DEFK3(mul64, OP_MUL64) DEFK3(add64, OP_ADD64) DEFK3(floor64, OP_FLOOR64) DEFK3(fract64, OP_FRACT64)
+// conversions between 32- and 64-bit registers: the result of one feeds the other, so a chain stays a chain
+#define DEFK4(name, OPS)                                                                                   \
+__global__ __launch_bounds__(256) void k_##name(float *out, unsigned long long *cyc, int iters) {          \
+    double d0 = threadIdx.x + 1.0, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3;                                  \
+    int i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3;                                           \
+    const unsigned long long t0 = __builtin_readcyclecounter();                                             \
+    for (int i = 0; i < iters; i++) {                                                                       \
+        REP8(asm volatile(OPS OPS : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }   \
+    const unsigned long long t1 = __builtin_readcyclecounter();                                             \
+    out[blockIdx.x * 256 + threadIdx.x] = (float)(d0 + d1 + d2 + d3) + (float)(i0 + i1 + i2 + i3);         \
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                       \
+}
+// 8 instructions per asm statement like the other bodies: four conversions each way
+#define OPS_CVT64 "v_cvt_f64_i32 %0, %4\n v_cvt_f64_i32 %1, %5\n v_cvt_f64_i32 %2, %6\n v_cvt_f64_i32 %3, %7\n"
+#define OPS_CVT32 "v_cvt_i32_f64 %4, %0\n v_cvt_i32_f64 %5, %1\n v_cvt_i32_f64 %6, %2\n v_cvt_i32_f64 %7, %3\n"
+DEFK4(cvt_f64_i32, OPS_CVT64) DEFK4(cvt_i32_f64, OPS_CVT32)
+
 typedef void (*kern_t)(float *, unsigned long long *, int);
 
 int main() {
@@ -83,6 +131,11 @@ int main() {
         {"v_cmp_le_f32 vcc", k_cmp}, {"v_cndmask_b32 (sgpr)", k_cnds}, {"v_cvt_i32_f32", k_cvt}, {"v_add_u32", k_addu},
         {"v_and_b32", k_andb}, {"v_lshlrev_b32", k_lshl}, {"v_mov_b32", k_mov}, {"v_rcp_f32", k_rcp},
         {"v_mad_u32_u24", k_madu}, {"v_bfe_u32", k_bfe},
+        {"v_sqrt_f32", k_sqrtf}, {"v_floor_f32", k_floorf}, {"v_rndne_f32", k_rndne}, {"v_cvt_f32_i32", k_cvtf},
+        {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_u32", k_mulhi}, {"v_mul_u32_u24", k_mul24}, {"v_sub_u32", k_subu},
+        {"v_cmp_lt_u32 vcc", k_cmpu}, {"v_cndmask_b32 (vcc)", k_cndv}, {"v_ffbh_u32", k_ffbh}, {"v_bcnt_u32_b32", k_bcnt},
+        {"v_fma_f64", k_fma64}, {"v_mul_f64", k_mul64}, {"v_add_f64", k_add64}, {"v_floor_f64", k_floor64}, {"v_fract_f64", k_fract64},
+        {"v_cvt_f64_i32", k_cvt_f64_i32}, {"v_cvt_i32_f64", k_cvt_i32_f64},
         {"v_pk_fma_f32", k_pkfma}, {"v_pk_fma_f32 clamp", k_pkfmacl}, {"v_pk_add_f32", k_pkadd}, {"v_pk_mul_f32", k_pkmul}};
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;

@@ -42,12 +42,65 @@ for name, txt, v, kern in ((f"{rnd}_pmc_exact.txt", txt0, v0, "raycast_svo_kerne
         f"# L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS) = {v['TCC_HIT_sum'] / (v['TCC_HIT_sum'] + v['TCC_MISS_sum']):.3f};  effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time\n"
         + txt)
 open(P(f"{rnd}_valu_issue.txt"), "w").write(open(g("valu_issue.txt")).read())
+
+
+def issue_intervals(path):
+    """SIMD issue interval (shader cycles per wave64 instruction) per opcode at 4 waves per SIMD, from the ubench table."""
+    out = {}
+    for line in open(path):
+        m = re.match(r"(v_\S+(?: clamp| vcc| \(sgpr\)| \(vcc\))?)\s+W=1.*?W=4\s+([0-9.]+)", line)
+        if m:
+            out[m.group(1).strip()] = float(m.group(2))
+    return out
+
+
+def time_weighted_issue(v, iv):
+    """VALU issue cycles of one launch = sum over instruction classes of (wave-level count) x (measured issue interval of that
+    class).  The class counters do not name every opcode (profiles/<round>_valu_classes.txt says which opcode lands where): INT32
+    mixes full-rate adds / logic with the slower shifts, multiplies and bit-field ops, and what no class counter sees (min / max /
+    compare / select / move, per the calibration) is `other`; both get a low and a high interval, the estimate is the middle."""
+    g = lambda k: v.get(k, 0.0)
+    total = g("SQ_INSTS_VALU")
+    fixed = [("FMA_F32", g("SQ_INSTS_VALU_FMA_F32"), iv["v_fma_f32"]), ("ADD_F32", g("SQ_INSTS_VALU_ADD_F32"), iv["v_add_f32"]),
+             ("MUL_F32", g("SQ_INSTS_VALU_MUL_F32"), iv["v_mul_f32"]), ("TRANS_F32", g("SQ_INSTS_VALU_TRANS_F32"), iv["v_rcp_f32"]),
+             ("CVT", g("SQ_INSTS_VALU_CVT"), iv["v_cvt_i32_f32"]),
+             ("FMA_F64", g("SQ_INSTS_VALU_FMA_F64"), iv.get("v_fma_f64", 2 * iv["v_fma_f32"])),
+             ("MUL_F64", g("SQ_INSTS_VALU_MUL_F64"), iv.get("v_mul_f64", 2 * iv["v_fma_f32"])),
+             ("ADD_F64", g("SQ_INSTS_VALU_ADD_F64"), iv.get("v_add_f64", 2 * iv["v_fma_f32"])),
+             ("TRANS_F64", g("SQ_INSTS_VALU_TRANS_F64"), 4 * iv["v_rcp_f32"])]
+    int32, int64 = g("SQ_INSTS_VALU_INT32"), g("SQ_INSTS_VALU_INT64")
+    other = max(0.0, total - sum(c for _, c, _ in fixed) - int32 - int64)
+    ranged = [("INT32", int32, iv["v_add_u32"], iv["v_mad_u32_u24"]),
+              ("INT64", int64, 2 * iv["v_add_u32"], 2 * iv["v_mad_u32_u24"]),
+              ("other (min/max/cmp/select/move ...)", other, iv["v_mov_b32"], iv["v_cndmask_b32 (sgpr)"])]
+    base = sum(c * i for _, c, i in fixed)
+    lo = base + sum(c * a for _, c, a, _ in ranged)
+    hi = base + sum(c * b for _, c, _, b in ranged)
+    rows = [dict(cls=n, insts=int(c), cycles_per_inst=i) for n, c, i in fixed] + \
+           [dict(cls=n, insts=int(c), cycles_per_inst=[a, b]) for n, c, a, b in ranged]
+    return dict(classes=rows, issue_cycles_lo=lo, issue_cycles_hi=hi, issue_cycles_mid=0.5 * (lo + hi), valu_insts=int(total))
+
+
+iv = issue_intervals(g("valu_issue.txt"))
+tw = time_weighted_issue(v0, iv) if "SQ_INSTS_VALU_FMA_F32" in v0 else None
+if tw:
+    simd_cycles = v0["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0     # cycles of one XCD x the chip's 1024 SIMDs
+    tw["simd_cycles_per_launch"] = simd_cycles
+    tw["frac_time_weighted"] = round(tw["issue_cycles_mid"] / simd_cycles, 4)
+    tw["frac_time_weighted_range"] = [round(tw["issue_cycles_lo"] / simd_cycles, 4), round(tw["issue_cycles_hi"] / simd_cycles, 4)]
+    tw["source"] = (f"class counts profiles/{rnd}_pmc_exact.txt (vclass passes) x issue intervals at 4 waves per SIMD of profiles/{rnd}_valu_issue.txt; "
+                    f"opcode -> class calibration profiles/{rnd}_valu_classes.txt; denominator GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs")
+if os.path.exists(g("valu_classes.txt")):
+    open(P(f"{rnd}_valu_classes.txt"), "w").write(
+        "# which SQ_INSTS_VALU_<class> counter counts which opcode on gfx950: rocprofv3 --pmc over tools/ubench/valu_issue (one opcode per kernel),\n"
+        "# share of the kernel's SQ_INSTS_VALU each class counter saw (tools/pmc_classify.py)\n" + open(g("valu_classes.txt")).read())
 hbm = int((2 * v0["FETCH_SIZE"] + v0["WRITE_SIZE"]) * 1024)
 json.dump({"kernel_source_hash": bench.kernel_source_hash(), "hbm_bytes_per_launch": hbm, "fetch_size_kib_raw": v0["FETCH_SIZE"],
            "write_size_kib_raw": v0["WRITE_SIZE"],
            "correction": "gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md HBM section: rocprofv3 reports half of wide coalesced reads; applied to all reads = upper bound), WRITE_SIZE as reported",
            "source": f"profiles/{rnd}_pmc_exact.txt (separate --pmc passes, kernel raycast_svo_kernel<true, false, true>, headline workload)",
            "valu_insts_per_launch": int(v0["SQ_INSTS_VALU"]), "valu_source": f"SQ_INSTS_VALU, profiles/{rnd}_pmc_exact.txt",
+           "valu_time_weighted": tw,
            "mode_b": {"hbm_bytes_per_launch": int((2 * v1["FETCH_SIZE"] + v1["WRITE_SIZE"]) * 1024), "valu_insts_per_launch": int(v1["SQ_INSTS_VALU"]),
                       "source": f"profiles/{rnd}_pmc_mode_b.txt"}},
           open(P("traffic_latest.json"), "w"), indent=1)

@@ -117,6 +117,7 @@ SIGNATURES = {
                                   C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(_u64p), _u64p]),
     "vrc_assign_octree_file": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_uint32)]),
     "vrc_scene_diamond_square": (C.c_int, [C.c_uint32, C.c_double, _u8p, _i8p]),
+    "vrc_scene_diamond_square_f64": (C.c_int, [C.c_uint32, C.c_double, C.POINTER(C.c_double)]),
     "vrc_build_heightfield": (C.c_int, [_H, C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_uint32, C.c_uint64,
                                        C.POINTER(BuildInfo)]),
     "vrc_octree_from_columns": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_uint32, C.POINTER(_u64p), _u64p, _u64p]),
@@ -313,6 +314,15 @@ def diamond_square(dim: int, corner_seed: float = 58.0, want_grid: bool = True):
     return height, grid
 
 
+def diamond_square_field(dim: int, corner_seed: float = 58.0) -> np.ndarray:
+    """The double field Map::GenerateHeightBitmap holds before Map.cpp:248 quantises it, float64[dim, dim] indexed [y, x]."""
+    field = np.zeros((dim, dim), dtype=np.float64)
+    rc = lib.vrc_scene_diamond_square_f64(dim, corner_seed, field.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != 0:
+        raise VrcError(f"vrc_scene_diamond_square_f64: {STATUS.get(rc, rc)}")
+    return field
+
+
 def octree_from_columns(depth: int, hi: np.ndarray, lo: Optional[np.ndarray] = None, layout: int = 2) -> "Octree":
     """vrc_octree_from_columns: the host twin of CLCaster.build_heightfield (layout 2 = VRC_LAYOUT_NO_PAGE_HEADERS, the
     layout the device builder emits)."""
@@ -397,10 +407,13 @@ class CLCaster:
     def init(self, device_ordinal: int = 0) -> bool:
         return self._ok(lib.vrc_create(device_ordinal, C.byref(self._h)))
 
-    def init_group(self, device_ordinals, band_rows: int = 8, own_copies: bool = False) -> bool:
+    def init_group(self, device_ordinals, band_rows: int = 8, own_copies: Optional[bool] = None) -> bool:
         """One host thread, several GPUs (vrc_create_group): this object becomes rank 0 of a row-sliced group.
-        own_copies (VRC_GROUP_OWN_COPIES): ranks on rank 0's GPU take the copy path of a rank on another GPU."""
+        own_copies (VRC_GROUP_OWN_COPIES): ranks on rank 0's GPU take the copy path of a rank on another GPU; None (the
+        default) leaves the choice to vrc_create_group, which honours VRC_GROUP_OWN_COPIES=1 in the environment like a C host."""
         d = np.ascontiguousarray(device_ordinals, dtype=np.int32)
+        if own_copies is None:
+            return self._ok(lib.vrc_create_group(_ptr(d, _i32p), d.size, band_rows, C.byref(self._h)))
         return self._ok(lib.vrc_create_group_ex(_ptr(d, _i32p), d.size, band_rows, 1 if own_copies else 0, C.byref(self._h)))
 
     def group_size(self) -> int:

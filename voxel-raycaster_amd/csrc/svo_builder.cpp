@@ -441,11 +441,10 @@ int vrc_scene_shell_terrain_attachments(uint32_t depth, uint64_t seed, uint32_t 
     return build_attachments(descriptors, n_descriptors, root_index, 1u << depth, mat, lookup, attachments, n_attachments);
 }
 
-int vrc_scene_diamond_square(uint32_t dim, double corner_seed, uint8_t *height, int8_t *grid) {
-    // (the dense grid is dim^3 bytes: 4096 at most; the height field alone goes up to 16384^2 doubles = 2 GiB of host memory)
-    if (!is_pow2(dim) || dim > (grid ? 4096u : 16384u) || !height) return VRC_ERR_INVALID_ARGUMENT;
-    const int n = (int)dim, size = n + 1;                     // Map.cpp:157 DATA_SIZE (samples wrap, :266-272)
-    std::vector<double> hm((size_t)n * n, 0.0);
+// the double field of Map::GenerateHeightBitmap before :248 quantises it
+static void diamond_square_field(int n, double corner_seed, std::vector<double> &hm) {
+    const int size = n + 1;                                    // Map.cpp:157 DATA_SIZE (samples wrap, :266-272)
+    hm.assign((size_t)n * n, 0.0);
     auto at = [&](int x, int y) -> double & { return hm[(size_t)(x & (n - 1)) + (size_t)(y & (n - 1)) * n]; };
     std::mt19937 gen;                                          // :146 default seed
     std::uniform_real_distribution<double> dis(-1.0, 1.0);    // :147
@@ -469,6 +468,22 @@ int vrc_scene_diamond_square(uint32_t dim, double corner_seed, uint8_t *height, 
                 if (y == 0) at(x, size - 1) = avg;
             }
     }
+}
+
+int vrc_scene_diamond_square_f64(uint32_t dim, double corner_seed, double *field) {
+    if (!is_pow2(dim) || dim > 16384u || !field) return VRC_ERR_INVALID_ARGUMENT;
+    std::vector<double> hm;
+    diamond_square_field((int)dim, corner_seed, hm);
+    std::copy(hm.begin(), hm.end(), field);
+    return VRC_OK;
+}
+
+int vrc_scene_diamond_square(uint32_t dim, double corner_seed, uint8_t *height, int8_t *grid) {
+    // (the dense grid is dim^3 bytes: 4096 at most; the height field alone goes up to 16384^2 doubles = 2 GiB of host memory)
+    if (!is_pow2(dim) || dim > (grid ? 4096u : 16384u) || !height) return VRC_ERR_INVALID_ARGUMENT;
+    const int n = (int)dim;
+    std::vector<double> hm;
+    diamond_square_field(n, corner_seed, hm);
     for (int y = 0; y < n; y++)
         for (int x = 0; x < n; x++)                            // :248 clamp to [0, dimensions.z]
             height[(size_t)x + (size_t)y * n] = (uint8_t)std::min(std::max(hm[(size_t)x + (size_t)y * n], 0.0), (double)std::min(n, 255));

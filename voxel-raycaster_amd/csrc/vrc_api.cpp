@@ -265,12 +265,19 @@ int ensure_hits(vrc_caster *h) {
 
 // Is this host address page-locked (hipHostMalloc / hipHostRegister)?  hipMemcpyAsync into pageable memory blocks the
 // calling thread copy by copy, which would serialise the tiles of a multi-GPU read-back.
-bool host_is_pinned(const void *p) {
+bool host_byte_is_pinned(const void *p) {
     hipPointerAttribute_t a;
     memset(&a, 0, sizeof(a));
     const hipError_t e = hipPointerGetAttributes(&a, p);
     (void)hipGetLastError();
     return e == hipSuccess && a.type == hipMemoryTypeHost;
+}
+// the whole destination [p, p + bytes) must be page-locked: a buffer pinned only in part (vrc_pin_host_buffer with a
+// smaller size, or a sub-range of a larger array) is treated as pageable and staged.  Registered ranges are contiguous,
+// and two adjacent registrations are still page-locked memory, so the first and the last byte decide.
+bool host_is_pinned(const void *p, size_t bytes) {
+    if (!p || !bytes) return false;
+    return host_byte_is_pinned(p) && host_byte_is_pinned((const char *)p + bytes - 1);
 }
 
 // device rows -> the caller's full-frame buffer, `bpp` bytes per pixel.  stage: copy into this rank's pinned staging
@@ -1005,7 +1012,7 @@ int compute_async_one(vrc_caster *h) {
 // still run side by side (a pageable hipMemcpyAsync blocks the host thread); a single handle copies directly.
 template <class Enqueue>
 int gather_rows(vrc_caster *h, void *host, size_t bpp, Enqueue enqueue) {
-    const bool stage = !h->peers.empty() && !host_is_pinned(host);
+    const bool stage = !h->peers.empty() && !host_is_pinned(host, bpp * (size_t)h->width * (size_t)h->height);
     int rc = enqueue(h, stage);
     if (rc != VRC_OK) return rc;
     for (size_t i = 0; i < h->peers.size(); i++) {
