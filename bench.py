@@ -517,7 +517,7 @@ def survey_camera_leg(sc, c, args):
     test_headline_size_frame_with_the_reference_bias_active).  `value` stays on the bias-free pose config.camera describes."""
     import torch
     pos = np.ascontiguousarray(sc["survey_cam_pos"], dtype=np.float32)
-    assert c.assign_camera(sc["cam_dir"], pos), c.last_error()
+    assert c.assign_camera(sc["cam_dir"], pos) and c.validate(), c.last_error()
     try:
         for _ in range(5):
             assert c.compute(), c.last_error()
@@ -532,7 +532,7 @@ def survey_camera_leg(sc, c, args):
         dt = time.perf_counter() - t0
         nl, ms = c.timing()
     finally:
-        assert c.assign_camera(sc["cam_dir"], sc["cam_pos"]), c.last_error()
+        assert c.assign_camera(sc["cam_dir"], sc["cam_pos"]) and c.validate(), c.last_error()
     return {"ms_per_step": round(dt / args.steps * 1e3, 4), "value": round(rays * args.steps / dt / 1e6, 3), "unit": "Mrays/s",
             "kernel_ms_avg": round(ms / max(nl, 1), 4), "rays_per_step": int(rays), "steps": ctr["steps"], "descriptor_reads": ctr["descriptor_reads"],
             "camera": {"position": [float(v) for v in pos], "octree_bias": 1, "note": "SURVEY 8d pose as written; the reference's bias term is non-zero here"}}

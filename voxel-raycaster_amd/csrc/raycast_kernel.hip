@@ -162,16 +162,20 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         // coherent with the others', so a slot handed from a block on one XCD to a block on another could be overwritten
         // by the first L2's late write-back after the second block's lines were evicted (seen as 1 frame in 4000 with a
         // few tie counts off by one when small frames made blocks look for slots anywhere; tests/soak_jumps_gpu.py).
-        // An eighth holds as many slots as an XCD holds blocks (vrc_api.cpp ensure_jump_cache), so the search always ends;
-        // the tables an XCD works on are lines its L2 already holds and rewrites in place.
+        // An eighth holds as many slots as an XCD holds blocks (vrc_api.cpp ensure_jump_cache sizes it from the device's CU
+        // count and threads per CU), so a free slot is always there; the search is bounded all the same -- after one full
+        // sweep of its eighth without a free slot (a part with more CUs per XCD, aliased XCC ids, a flag a killed launch left
+        // set) the block gives up and steps voxel by voxel, which renders the same frame.
+        // The tables an XCD works on are lines its L2 already holds and rewrites in place.
         const unsigned per = (unsigned)p.jump_slot_count >> 3;
         const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(kHwRegXccId) & 7u;
         const unsigned lo = xcc * per, hi = lo + per;
-        unsigned i = lo + (unsigned)(((unsigned long long)(blockIdx.x >> 3) * 2654435761ULL) % per);
+        unsigned i = lo + (unsigned)(((unsigned long long)(blockIdx.x >> 3) * 2654435761ULL) % per), tries = 0;
         while (atomicCAS(&p.jump_slots[i], 0u, 1u) != 0u) {
             if (++i == hi) i = lo;
+            if (++tries >= per) { i = 0xffffffffu; break; }
         }
-        s_jump_slot = (int)i;
+        s_jump_slot = (int)i;                             // -1: no slot
     }
     __syncthreads();
 
@@ -279,7 +283,8 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     // and the bit mask of the rows built for the ray's current direction
     uint32_t *jtab = nullptr;
     uint32_t jrows = 0;
-    if (kJump) jtab = p.jump_cache + ((size_t)s_jump_slot * kTilesPerBlock + (tid >> 6)) * (size_t)(kJumpTableDwords * 64) + (tid & 63);
+    const bool has_slot = kJump && s_jump_slot >= 0;      // (block-uniform)
+    if (has_slot) jtab = p.jump_cache + ((size_t)s_jump_slot * kTilesPerBlock + (tid >> 6)) * (size_t)(kJumpTableDwords * 64) + (tid & 63);
 
     if (in_image) {
         if (!ray_setup(r, p, pix)) {
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                 X = fminf(X, fminf(fminf(jump_axis_limit(r.itx, r.dtx), jump_axis_limit(r.ity, r.dty)), jump_axis_limit(r.itz, r.dtz)));
                 const float est = fmaxf(0.0f, fmaf(X - r.itx, fabsf(r.rdx), 1.0f)) + fmaxf(0.0f, fmaf(X - r.ity, fabsf(r.rdy), 1.0f)) +
                                   fmaxf(0.0f, fmaf(X - r.itz, fabsf(r.rdz), 1.0f));
-                want = est >= jump_min_run;
+                want = has_slot && est >= jump_min_run;
             }
             const unsigned long long wj = __ballot(want);
             VRC_TICK(0);
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
 #endif
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
     publish_counters(p, block_ctr, vals);                 // (a __syncthreads inside: every wave of the block is through with its tables)
-    if (kJump && tid == 0) atomicExch(&p.jump_slots[s_jump_slot], 0u);
+    if (kJump && tid == 0 && s_jump_slot >= 0) atomicExch(&p.jump_slots[s_jump_slot], 0u);
 }
 
 __global__ void reduce_counters_kernel(const unsigned long long *partials, int nblocks, unsigned long long *out) {

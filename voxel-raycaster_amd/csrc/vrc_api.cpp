@@ -243,8 +243,15 @@ int install_viewport(vrc_caster *h, int32_t width, int32_t height, const float *
 // block SLOT.  Only resident blocks hold a slot (the kernel takes and returns them), so the buffer is sized for the chip,
 // not for the frame: at most kJumpSlots slots of 12 KB.
 int ensure_jump_cache(vrc_caster *h, int nblocks) {
-    // an eighth of the slots per XCD, each eighth at least as large as the number of blocks one XCD can hold at a time
-    const int slots = 8 * std::max(1, std::min(nblocks, vrc::kJumpSlotsPerXcd));
+    // an eighth of the slots per XCD, each eighth at least as large as the number of blocks one XCD can hold at a time: its
+    // CUs x the 256-thread blocks a CU holds at most (MI355X: 32 x 8 = kJumpSlotsPerXcd; a larger part gets larger eighths, and
+    // the kernel's slot search is bounded in any case)
+    int cus = 0, threads_per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
+    if (hipDeviceGetAttribute(&threads_per_cu, hipDeviceAttributeMaxThreadsPerMultiProcessor, h->device) != hipSuccess) threads_per_cu = 2048;
+    (void)hipGetLastError();
+    const int per_xcd = std::max(vrc::kJumpSlotsPerXcd, ((cus + 7) / 8) * std::max(1, threads_per_cu / vrc::kBlockThreads));
+    const int slots = 8 * std::max(1, std::min(nblocks, per_xcd));
     if (h->d_jump_cache && h->jump_slot_count >= slots) return VRC_OK;
     release(h->d_jump_cache); release(h->d_jump_slots);
     h->jump_slot_count = 0;
