@@ -145,7 +145,9 @@ VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
 //   bits 0-23  s: s * inc_a == g (mod inc_b), 0 <= s < inc_b        bits 24-31  g = gcd(inc_a, inc_b)
 //   g == 255: the gcd is 255 or more and the pair is solved afresh when it is needed (0.4 % of the pairs; with the full gcd
 //   in a second dword those on-the-spot runs disappear, but the wider rows cost as much as they save: 2.54-2.57 ms either
-//   way, 88 instead of 72 bytes of scratch, 1.0 instead of 0.67 GB of HBM traffic per frame);  whole dword 0: no entry
+//   way, 88 instead of 72 bytes of scratch, 1.0 instead of 0.67 GB of HBM traffic per frame.  Round 4: s is only needed modulo
+//   inc_b / g, so s and g always fit one dword with a variable split (5 bits of length, then g, then s): no on-the-spot runs
+//   left, bit-identical, and 4 % SLOWER -- 2.67 vs 2.57 ms -- dropped);  whole dword 0: no entry
 // The increments depend on (delta_t, binade) only.  In HBM (RaycastParams::jump_cache), one table per lane, interleaved
 // over the 64 lanes of a wave (stride 64) so that a row is one coalesced 256-byte line.
 // ---------------------------------------------------------------------------------------------------------------
@@ -154,8 +156,18 @@ VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
 #endif
 constexpr int kJumpFirstBinade = 127 + VRC_JUMP_FIRST_LOG2;   // no table below t = 128: a binade of fewer voxels than a Euclid run costs
 constexpr int kJumpBinades = 12;              // t < 2^19
-constexpr int kJumpRing = 4;                  // rows kept per ray: a ring indexed by row % kJumpRing (intersection_t only grows)
-constexpr int kJumpTableDwords = 3 * kJumpRing;   // one dword per pair and row
+#ifndef VRC_JUMP_RING
+#define VRC_JUMP_RING 4
+#endif
+// rows kept per ray: a ring indexed by row % R (intersection_t only grows).  The functions below take R as a template
+// argument: 4 rows for tables in global memory, 3 rows -- 3 x 3 dwords x 256 threads = 9 KB per block -- for tables in LDS,
+// which is what fits beside the traversal stack of a depth-12 tree at 5 blocks per CU (round 4).  On the headline frame 3 and
+// 4 rows run the same; deep trees (rays that cross more binades) lose 3-4 % with 3.
+constexpr int kJumpRing = VRC_JUMP_RING;      // the default R (host harness: -DVRC_JUMP_RING=3 / 4)
+template <int R> struct JumpRingMask;
+template <> struct JumpRingMask<3> { static constexpr uint32_t value = 0x09249249u; };   // a bit every R rows
+template <> struct JumpRingMask<4> { static constexpr uint32_t value = 0x11111111u; };
+constexpr int kJumpTableDwords = 3 * kJumpRing;   // one dword per pair and row (default ring)
 
 // s and g with s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib; 1 <= ia, ib < 2^24.  Extended Euclid on exact integers
 // held in floats, two steps per trip with the roles of the two remainders alternating (no conditional swaps):
@@ -203,6 +215,7 @@ VRC_HD uint32_t jump_entry_pack(int32_t s, int32_t g) { return (uint32_t)s | ((u
 
 // Builds one row (binade kJumpFirstBinade + row, the three pairs) of the table of every lane with `active` set; the
 // other lanes idle through the loop.  A pair one of whose axes cannot have a progression in that binade gets "no entry".
+template <int R = kJumpRing>
 VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float dz, uint32_t *tab, int stride, uint32_t &solves) {
     const int32_t e = kJumpFirstBinade + row;
     const bool okx = active && jump_binade_ok(e, dx), oky = active && jump_binade_ok(e, dy), okz = active && jump_binade_ok(e, dz);
@@ -217,7 +230,7 @@ VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float
     }
     if (active) {
         int32_t s, g;
-        const int slot = row % kJumpRing;
+        const int slot = row % R;
         euclid_finish(cxy, iy, s, g); tab[(3 * slot + 0) * stride] = vxy ? jump_entry_pack(s, g) : 0u;
         euclid_finish(cxz, iz, s, g); tab[(3 * slot + 1) * stride] = vxz ? jump_entry_pack(s, g) : 0u;
         euclid_finish(cyz, iz, s, g); tab[(3 * slot + 2) * stride] = vyz ? jump_entry_pack(s, g) : 0u;
@@ -238,6 +251,7 @@ VRC_HD uint32_t jump_rows_needed(float tx, float ty, float tz) {
 // While a wanting lane lacks a row it needs, that row is built for EVERY live lane that lacks it (the rays of a tile reach
 // a binade within a few rounds of each other, and the Euclid loop costs the same for one lane as for 64).  `rows`: this
 // lane's bit mask of built rows (cleared when the ray changes direction).
+template <int R = kJumpRing>
 VRC_HD void jump_rows_build(bool want, bool live, uint32_t &rows, float tx, float ty, float tz, float dx, float dy, float dz,
                             uint32_t *tab, int stride, uint32_t &solves) {
     uint32_t need = want ? (jump_rows_needed(tx, ty, tz) & ~rows) : 0u;
@@ -252,13 +266,13 @@ VRC_HD void jump_rows_build(bool want, bool live, uint32_t &rows, float tx, floa
         // a lane that asked for the row gets it whatever it evicts (the loop must end; a pair whose row was evicted is
         // solved on the spot by stretch_jump); a lane that merely rides along takes it only if the row lies in the window of
         // kJumpRing rows from the binade it is in -- further ahead it would evict a row the ray still uses
-        const bool build = live && !((rows >> row) & 1u) && (((need >> row) & 1u) || (row >= lo_row && row - lo_row < kJumpRing));
-        jump_table_build_row(build, row, dx, dy, dz, tab, stride, solves);
-        if (build) rows = (rows & ~(0x11111111u << (row % kJumpRing))) | (1u << row);   // the rows that shared its ring slot are gone
-        static_assert(kJumpRing == 4, "the slot mask above has a bit every kJumpRing rows");
+        const bool build = live && !((rows >> row) & 1u) && (((need >> row) & 1u) || (row >= lo_row && row - lo_row < R));
+        jump_table_build_row<R>(build, row, dx, dy, dz, tab, stride, solves);
+        if (build) rows = (rows & ~(JumpRingMask<R>::value << (row % R))) | (1u << row);   // the rows that shared its ring slot are gone
         need &= ~rows;
     }
 }
+template <int R = kJumpRing>
 VRC_HD JumpEntry jump_table_entry(const uint32_t *tab, int stride, uint32_t rows, int pair, int32_t e) {
     const uint32_t row = (uint32_t)(e - kJumpFirstBinade);
     const bool have = row < (uint32_t)kJumpBinades && ((rows >> (row & 31u)) & 1u);
@@ -269,7 +283,7 @@ VRC_HD JumpEntry jump_table_entry(const uint32_t *tab, int stride, uint32_t rows
     return en;
 #endif
     if (have) {
-        const uint32_t d = tab[(3 * (int)(row % (uint32_t)kJumpRing) + pair) * stride];
+        const uint32_t d = tab[(3 * (int)(row % (uint32_t)R) + pair) * stride];
         en.s = (int32_t)(d & 0xffffffu); en.g = (int32_t)(d >> 24);
     }
     return en;
@@ -413,13 +427,14 @@ struct JumpOut {
 
 // One exact multi-iteration jump.  t*, n* (countdowns >= 1) are updated in place.  `left` = iterations the loop may
 // still run (max_distance - distance_traveled, >= 1).  `tab`, `stride`, `rows`: the ray's table (jump_rows_build).
+template <int R = kJumpRing>
 VRC_HD JumpOut stretch_jump(float &tx, float &ty, float &tz, float dx, float dy, float dz, int32_t &nx, int32_t &ny,
                             int32_t &nz, int32_t left, const uint32_t *tab, int stride, uint32_t rows) {
     // the table dwords first: their addresses need the exponents only, and the loads have the whole decode to arrive
     const int32_t ex0 = (int32_t)(f2u(tx) >> 23), ey0 = (int32_t)(f2u(ty) >> 23), ez0 = (int32_t)(f2u(tz) >> 23);
-    const JumpEntry txy = jump_table_entry(tab, stride, ex0 == ey0 ? rows : 0u, 0, ex0);
-    const JumpEntry txz = jump_table_entry(tab, stride, ex0 == ez0 ? rows : 0u, 1, ex0);
-    const JumpEntry tyz = jump_table_entry(tab, stride, ey0 == ez0 ? rows : 0u, 2, ey0);
+    const JumpEntry txy = jump_table_entry<R>(tab, stride, ex0 == ey0 ? rows : 0u, 0, ex0);
+    const JumpEntry txz = jump_table_entry<R>(tab, stride, ex0 == ez0 ? rows : 0u, 1, ex0);
+    const JumpEntry tyz = jump_table_entry<R>(tab, stride, ey0 == ez0 ? rows : 0u, 2, ey0);
     JumpAxis ax = jump_axis(tx, dx, nx), ay = jump_axis(ty, dy, ny), az = jump_axis(tz, dz, nz);
     float X = ax.E < ay.E ? ax.E : ay.E;
     X = X < az.E ? X : az.E;

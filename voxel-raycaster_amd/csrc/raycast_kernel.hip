@@ -42,7 +42,7 @@
 
 namespace vrc {
 
-static_assert(kJumpTableDwords == kJumpTableDwordsPerLane, "vrc_api.cpp sizes the Euclid tables with kJumpTableDwordsPerLane");
+static_assert(3 * 4 == kJumpTableDwordsPerLane, "vrc_api.cpp sizes the global Euclid tables (4 ring rows x 3 pairs) with kJumpTableDwordsPerLane");
 
 // Packed stack entry of one descriptor level:
 //   bits 0-7 valid mask, 8-15 leaf mask, 16-63 absolute index of the first kept child
@@ -148,14 +148,21 @@ __device__ unsigned long long g_time_stats[16];
 #endif
 // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): (size - 1) << 11 | offset << 6 | register id 20; the XCD this wave runs on, 0..7
 constexpr int kHwRegXccId = (3 << 11) | (0 << 6) | 20;
-template <bool kJump, bool kMulti, bool kTuned>
+// kLdsTab: the Euclid tables of the jumps live in LDS behind the traversal stack ([ring row][pair][thread], 9 KB per block)
+//         instead of in the global table buffer -- chosen by the launch when stack + tables of 5 blocks fit the CU's LDS
+//         (depth <= 12): no slot to take, 12 bytes less scratch, 2.57 -> 2.51 ms on the headline frame; deeper trees keep the
+//         global tables (with the rows in LDS they would run at 4 blocks per CU: depth 13 3.36 -> 3.56 ms, depth 16 6.85 -> 7.42)
+template <bool kJump, bool kMulti, bool kTuned, bool kLdsTab = false>
 __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
+    static_assert(kJump || !kLdsTab, "tables exist for the jump instances only");
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
     __shared__ unsigned long long block_ctr[kCtrCount];
     __shared__ int s_jump_slot;
     const int tid = threadIdx.x;
     if (tid < kCtrCount) block_ctr[tid] = 0;
-    if (kJump && tid == 0) {
+    if (kLdsTab) {
+        if (tid == 0) s_jump_slot = 0;
+    } else if (kJump && tid == 0) {
         // the block's slot in the table buffer: tables exist for RESIDENT blocks only (they stay in the L2 / MALL), so a
         // block takes a free slot when it starts and gives it back at its end.  The slots are divided among the XCDs and a
         // block only ever takes one of the XCD it RUNS on (HW_REG_XCC_ID, not a guess from blockIdx): an XCD's L2 is not
@@ -283,8 +290,11 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     // and the bit mask of the rows built for the ray's current direction
     uint32_t *jtab = nullptr;
     uint32_t jrows = 0;
-    const bool has_slot = kJump && s_jump_slot >= 0;      // (block-uniform)
-    if (has_slot) jtab = p.jump_cache + ((size_t)s_jump_slot * kTilesPerBlock + (tid >> 6)) * (size_t)(kJumpTableDwords * 64) + (tid & 63);
+    // rows in LDS: behind the traversal stack, [ring row][pair][thread], one dword each (consecutive threads, consecutive banks)
+    constexpr int kRing = kLdsTab ? 3 : 4;               // table rows per ray (exact_jump.hpp)
+    const int jstride = kLdsTab ? kBlockThreads : 64;
+    if (kLdsTab) jtab = reinterpret_cast<uint32_t *>(lds_stack + (size_t)(p.log2_dim > 1 ? p.log2_dim - 1 : 1) * kBlockThreads) + tid;
+    else if (kJump && s_jump_slot >= 0) jtab = p.jump_cache + ((size_t)s_jump_slot * kTilesPerBlock + (tid >> 6)) * (size_t)(3 * kRing * 64) + (tid & 63);
 
     if (in_image) {
         if (!ray_setup(r, p, pix)) {
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     const bool use_safe = kTuned ? true : p.safe_run != 0;
     const bool use_single = kTuned ? true : p.single_step != 0;
     const int shade_threshold = kTuned ? kDefaultShadeThreshold : p.shade_threshold;
-    const float jump_min_run = kTuned ? (float)kDefaultJumpMinRun : (float)p.jump_min_run;   // estimated iterations that make a jump worth its block
+    const float jump_min_run = kTuned ? (float)(kLdsTab ? kDefaultJumpMinRunLds : kDefaultJumpMinRun) : (float)p.jump_min_run;   // estimated iterations that make a jump worth its block
     const int safe_cap = kTuned ? kDefaultSafeSteps : p.safe_steps;   // iterations per safe run (phase 2a)
     const int burst_cap = kTuned ? kDefaultBurstSteps : p.burst_steps;   // ordinary steps per round and lane (compare/select loop)
     const int exact_cap = (use_arith && use_safe) ? (kTuned ? kDefaultExactSteps : p.exact_steps) : burst_cap;
@@ -352,7 +362,9 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                 X = fminf(X, fminf(fminf(jump_axis_limit(r.itx, r.dtx), jump_axis_limit(r.ity, r.dty)), jump_axis_limit(r.itz, r.dtz)));
                 const float est = fmaxf(0.0f, fmaf(X - r.itx, fabsf(r.rdx), 1.0f)) + fmaxf(0.0f, fmaf(X - r.ity, fabsf(r.rdy), 1.0f)) +
                                   fmaxf(0.0f, fmaf(X - r.itz, fabsf(r.rdz), 1.0f));
-                want = has_slot && est >= jump_min_run;
+                // (a block that found no table slot has no table: it never jumps.  Tested on the pointer, which is live anyway:
+                // one more value held through the loop costs this kernel 2 % in spills)
+                want = (kLdsTab || jtab != nullptr) && est >= jump_min_run;
             }
             const unsigned long long wj = __ballot(want);
             VRC_TICK(0);
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                     uint32_t solves = 0;
                     asm volatile("; VRC_MARK jump_rows_begin");
 #ifndef VRC_JUMP_NO_FILL   // (timing experiment only, with VRC_JUMP_NO_TIES)
-                    jump_rows_build(want, mode == kStep || mode == kEvent, jrows, r.itx, r.ity, r.itz, r.dtx, r.dty, r.dtz, jtab, 64, solves);
+                    jump_rows_build<kRing>(want, mode == kStep || mode == kEvent, jrows, r.itx, r.ity, r.itz, r.dtx, r.dty, r.dtz, jtab, jstride, solves);
 #endif
                     asm volatile("; VRC_MARK jump_rows_end");
                     VRC_TICK(1);
@@ -381,8 +393,8 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                 if (want) {
                     asm volatile("; VRC_MARK jump_block_begin");
                     int inx = (int)nx, iny = (int)ny, inz = (int)nz;
-                    const JumpOut jo = stretch_jump(r.itx, r.ity, r.itz, r.dtx, r.dty, r.dtz, inx, iny, inz,
-                                                    r.max_distance - r.distance_traveled, jtab, 64, jrows);
+                    const JumpOut jo = stretch_jump<kRing>(r.itx, r.ity, r.itz, r.dtx, r.dty, r.dtz, inx, iny, inz,
+                                                    r.max_distance - r.distance_traveled, jtab, jstride, jrows);
 #ifdef VRC_SCHED_STATS
                     atomicAdd(&g_jump_stats[1], 1ULL);
                     atomicAdd(&g_jump_stats[2], (unsigned long long)jo.iterations);
@@ -725,7 +737,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
 #endif
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
     publish_counters(p, block_ctr, vals);                 // (a __syncthreads inside: every wave of the block is through with its tables)
-    if (kJump && tid == 0 && s_jump_slot >= 0) atomicExch(&p.jump_slots[s_jump_slot], 0u);
+    if (kJump && !kLdsTab && tid == 0 && s_jump_slot >= 0) atomicExch(&p.jump_slots[s_jump_slot], 0u);
 }
 
 __global__ void reduce_counters_kernel(const unsigned long long *partials, int nblocks, unsigned long long *out) {
@@ -843,22 +855,55 @@ hipError_t launch_frame_setup(const RaycastParams &p, hipStream_t stream) {
 
 hipError_t launch_raycast_jump(const RaycastParams &p, hipStream_t stream);   // raycast_jump_kernel.hip
 
+// dynamic LDS of the SVO kernel: the traversal stack, and behind it the jump tables when they live in LDS
+static size_t svo_stack_bytes(const RaycastParams &p) {
+    const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
+    return (size_t)levels * kBlockThreads * sizeof(uint64_t) + (size_t)p.lds_pad_bytes;
+}
+constexpr size_t kLdsTabBytes = (size_t)(3 * 3) * kBlockThreads * sizeof(uint32_t);   // 3 ring rows x 3 pairs, one dword per thread
+
+// Do the Euclid tables of this frame live in LDS?  Yes when the jump instance with stack + tables still reaches the blocks
+// per CU its registers allow (VRC_MIN_BLOCKS_JUMP) -- asked of the runtime once per LDS size; setting jump_tables_lds = 0 / 1
+// overrides (2 = this rule).  vrc_api.cpp asks the same question to know whether the global table buffer is needed.
+bool jump_tables_in_lds(const RaycastParams &p) {
+    if (!p.svo || p.stepping_mode != 0) return false;
+    if (p.jump_tables_lds == 0) return false;
+    if (p.jump_tables_lds == 1) return true;
+    const size_t lds = svo_stack_bytes(p) + kLdsTabBytes;
+    static size_t cached_lds = ~(size_t)0;
+    static bool cached = false;
+    if (cached_lds != lds) {
+        int per_cu = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true>),
+                                                                          kBlockThreads, lds);
+        (void)hipGetLastError();
+        cached = e == hipSuccess && per_cu >= VRC_MIN_BLOCKS_JUMP;
+        cached_lds = lds;
+    }
+    return cached;
+}
+
 hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
     (void)hipGetLastError();                 // an error an earlier call left behind is not this launch's
     const int nblocks = p.blocks_x * p.local_tile_rows;
     if (nblocks <= 0) return hipSuccess;
     if (p.svo && p.stepping_mode == 1) return launch_raycast_jump(p, stream);
     if (p.svo) {
-        const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
-        const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t) + (size_t)p.lds_pad_bytes;
         const bool jump = p.jump_min_run < kJumpOff, multi = p.light_count > 1;
-        const bool tuned = (!jump || p.jump_min_run == kDefaultJumpMinRun) &&
+        const bool lds_tab = jump && jump_tables_in_lds(p);
+        const size_t lds = svo_stack_bytes(p) + (lds_tab ? kLdsTabBytes : 0);
+        const bool tuned = (!jump || p.jump_min_run == (lds_tab ? kDefaultJumpMinRunLds : kDefaultJumpMinRun)) &&
                            p.widen_nodes != 0 && p.arith_mask != 0 && p.safe_run != 0 && p.single_step != 0 &&
                            p.shade_threshold == kDefaultShadeThreshold && p.safe_steps == kDefaultSafeSteps &&
                            p.exact_steps == kDefaultExactSteps && p.burst_steps == kDefaultBurstSteps;
-        if (jump && (!p.jump_cache || !p.jump_slots || p.jump_slot_count < 1)) return hipErrorInvalidValue;
-#define VRC_LAUNCH(J, M, T) hipLaunchKernelGGL((raycast_svo_kernel<J, M, T>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p)
-        if (jump) {
+        if (jump && !lds_tab && (!p.jump_cache || !p.jump_slots || p.jump_slot_count < 1)) return hipErrorInvalidValue;
+#define VRC_LAUNCH(...) hipLaunchKernelGGL((raycast_svo_kernel<__VA_ARGS__>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p)
+        if (lds_tab) {
+            if (multi && tuned) VRC_LAUNCH(true, true, true, true);
+            else if (multi) VRC_LAUNCH(true, true, false, true);
+            else if (tuned) VRC_LAUNCH(true, false, true, true);
+            else VRC_LAUNCH(true, false, false, true);
+        } else if (jump) {
             if (multi && tuned) VRC_LAUNCH(true, true, true);
             else if (multi) VRC_LAUNCH(true, true, false);
             else if (tuned) VRC_LAUNCH(true, false, true);

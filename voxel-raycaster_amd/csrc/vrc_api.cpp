@@ -25,6 +25,7 @@
 
 namespace vrc {
 hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream);
+bool jump_tables_in_lds(const RaycastParams &p);
 hipError_t launch_frame_setup(const RaycastParams &p, hipStream_t stream);
 hipError_t launch_reduce_counters(const unsigned long long *partials, int nblocks, unsigned long long *out,
                                   hipStream_t stream);
@@ -952,8 +953,6 @@ int compute_async_one(vrc_caster *h) {
     // wave scheduling knobs of the SVO kernel; they never change results
     p.burst_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "burst_steps", vrc::kDefaultBurstSteps)));
     p.shade_threshold = std::min<int64_t>(64, std::max<int64_t>(1, setting_or(h, "shade_threshold", vrc::kDefaultShadeThreshold)));
-    p.jump_min_run = (int32_t)std::min<int64_t>(vrc::kJumpOff, std::max<int64_t>(1, setting_or(h, "jump_min_run",
-                                    p.log2_dim >= vrc::kDefaultJumpMinDepth ? vrc::kDefaultJumpMinRun : vrc::kJumpOff)));
 
     p.widen_nodes = (int32_t)setting_or(h, "widen_nodes", 1);
     p.octree_bias = (int32_t)setting_or(h, "octree_bias", 1);
@@ -992,7 +991,14 @@ int compute_async_one(vrc_caster *h) {
         h->partial_blocks = nblocks;
     }
     p.counters = h->d_partials;
-    if (svo && p.stepping_mode == 0 && p.jump_min_run < vrc::kJumpOff) {
+    // exact closed-form jumps: on from depth 12; the threshold depends on where the Euclid tables live (LDS when stack + tables
+    // fit at full occupancy: depth 12)
+    p.jump_tables_lds = (int32_t)std::min<int64_t>(2, std::max<int64_t>(0, setting_or(h, "jump_tables_lds", 2)));
+    const bool tables_in_lds = vrc::jump_tables_in_lds(p);
+    p.jump_min_run = (int32_t)std::min<int64_t>(vrc::kJumpOff, std::max<int64_t>(1, setting_or(h, "jump_min_run",
+                                    p.log2_dim >= vrc::kDefaultJumpMinDepth ? (tables_in_lds ? vrc::kDefaultJumpMinRunLds : vrc::kDefaultJumpMinRun)
+                                                                            : vrc::kJumpOff)));
+    if (svo && p.stepping_mode == 0 && p.jump_min_run < vrc::kJumpOff && !tables_in_lds) {
         const int rc = ensure_jump_cache(h, nblocks);
         if (rc != VRC_OK) return rc;
         p.jump_cache = h->d_jump_cache; p.jump_slots = h->d_jump_slots; p.jump_slot_count = h->jump_slot_count;

@@ -23,7 +23,16 @@ constexpr int kBlockThreads = 64 * kTilesPerBlock;
 constexpr int kDefaultBurstSteps = 48, kDefaultShadeThreshold = 64, kDefaultSafeSteps = 64, kDefaultExactSteps = 16;
 // exact closed-form jumps (exact_jump.hpp): estimated iterations from which a lane asks for the jump block, and the tree
 // depth from which they are on by default (measured: depth 10 loses 15 %, depth 12 gains 15 %, depth 16 is 3.3x faster)
-constexpr int kDefaultJumpMinRun = 96, kDefaultJumpMinDepth = 12;
+#ifndef VRC_DEFAULT_JUMP_MIN_RUN
+#define VRC_DEFAULT_JUMP_MIN_RUN 96
+#endif
+constexpr int kDefaultJumpMinRun = VRC_DEFAULT_JUMP_MIN_RUN, kDefaultJumpMinDepth = 12;
+// ... and with the tables in LDS (depth 12: stack + tables fit at 5 blocks per CU) a jump is cheaper: 48 / 64 / 96 / 128 measured
+// 2.56 / 2.50 / 2.52 / 2.53 ms on the headline frame (round 4)
+#ifndef VRC_DEFAULT_JUMP_MIN_RUN_LDS
+#define VRC_DEFAULT_JUMP_MIN_RUN_LDS 64
+#endif
+constexpr int kDefaultJumpMinRunLds = VRC_DEFAULT_JUMP_MIN_RUN_LDS;
 constexpr int kJumpOff = 1 << 24;      // jump_min_run >= this: the instances without the jump block
 constexpr int kJumpTableDwordsPerLane = 12;   // == kJumpTableDwords of exact_jump.hpp (checked in raycast_kernel.hip)
 constexpr int kJumpSlotsPerXcd = 256;         // table slots per XCD: 32 CUs x 8 blocks, the most 256-thread blocks an XCD can hold at any occupancy
@@ -86,6 +95,7 @@ struct RaycastParams {
     uint32_t *jump_cache;             // the per-ray Euclid tables of exact_jump.hpp: kJumpTableDwordsPerLane dwords per lane of a block slot
     uint32_t *jump_slots;             // one flag per block slot (0 free / 1 taken): a block takes a slot when it starts
     int32_t jump_slot_count;
+    int32_t jump_tables_lds;          // 2: the tables live in LDS when stack + tables fit at full occupancy (depth <= 12), 1 / 0: always / never
     int32_t lds_pad_bytes;            // experiment knob: extra dynamic LDS to lower occupancy
     int32_t xcd_mode;                 // block->tile map: 0 contiguous eighth per XCD, 1 tile rows interleaved over XCDs, 2 none
     // row tiling (multi-GPU)
