@@ -365,6 +365,9 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                 // (a block that found no table slot has no table: it never jumps.  Tested on the pointer, which is live anyway:
                 // one more value held through the loop costs this kernel 2 % in spills)
                 want = (kLdsTab || jtab != nullptr) && est >= jump_min_run;
+                // (round 4: a second, lower threshold for lanes whose three t are all inside the table's binades -- "always jump once
+                // t >= 128" -- 1 / 8 / 24 iterations: 2.57 / 2.63 / 2.56 ms against 2.50: the pass, ~500 instructions on its straight
+                // path, is what a short run cannot pay for, not the Euclid runs)
             }
             const unsigned long long wj = __ballot(want);
             VRC_TICK(0);

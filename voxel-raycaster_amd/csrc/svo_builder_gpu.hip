@@ -212,9 +212,13 @@ __global__ void scatter_kernel(const uint64_t *__restrict__ kv, uint64_t n, uint
 }
 
 // Octree::GetVoxel(position).found (src/map/Octree.cpp:45-158); the octant at each level is one bit of each coordinate.
-// (A first version kept the reference's running 64-bit box corner and compared against it: inside validate_grid_kernel that
-// form returned run-to-run different answers on a static tree -- hipcc 7.2, gfx950 -- while this one is stable; the
-// column validator never showed it.)
+// (A first, never committed version kept the reference's running 64-bit box corner and compared against it; inside the
+// validate_grid_kernel of that day it returned run-to-run different answers and was replaced by this form.  Round 4 put both
+// forms into a kernel of their own -- tools/repro/tree_walk_repro.hip: every voxel of nine static trees with page headers
+// and far pointers, 25 runs each, -O3 and -O0, launches serialised -- and they agree with the grid, with each other and from
+// run to run (profiles/r04_tree_walk_repro.txt).  The walk was not the cause; what was unstable then was its input, i.e. the
+// order of the builder's passes in that unfinished state.  Both walks read only `desc`, written by kernels that precede them
+// on the same stream with a stream synchronisation in between.)
 __device__ __forceinline__ int tree_holds(const uint64_t *desc, uint64_t root_index, int depth, uint32_t x, uint32_t y, uint32_t z) {
     uint64_t index = root_index, d = desc[index];
     for (int l = depth - 1;; l--) {                            // l = log2 of the child's size
