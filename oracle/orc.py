@@ -52,7 +52,7 @@ class Scene(C.Structure):
         ("attachment_lookup", C.POINTER(C.c_uint32)), ("attachments", _u64p),
         ("octree_dimensions", C.c_int64), ("using_octree", C.c_int64), ("octree_root_index", C.c_int64),
         ("max_distance", C.c_int32), ("shadow_rays", C.c_int32), ("no_bias", C.c_int32), ("active_lights", C.c_int32),
-        ("cam_trig", C.c_float * 4), ("stepping_mode", C.c_int32),
+        ("cam_trig", C.c_float * 4), ("stepping_mode", C.c_int32), ("coarse_log2", C.c_int32),
         ("desc_pages", C.POINTER(C.c_void_p)), ("desc_page_fetch", C.c_void_p), ("desc_page_user", C.c_void_p)]
 
 
@@ -171,7 +171,7 @@ def camera_trig(cam_dir) -> np.ndarray:
 def raycast(*, width, height, cam_dir, cam_pos, lights, atlas, tile_dim, descriptors, root_index, octree_dim,
             using_octree, grid=None, map_dim=None, max_distance=20, shadow_rays=1, viewport=None, trig=None,
             rows=None, threads=1, want_hits=True, attachment_lookup=None, attachments=None, active_lights=1, no_bias=0,
-            stepping_mode=0):
+            stepping_mode=0, coarse_log2=-1):
     """Render with the oracle.  Returns (image[h,w,4] f32, hits[h,w,8] i32 or None, counters dict)."""
     keep = []
     s = Scene()
@@ -220,6 +220,7 @@ def raycast(*, width, height, cam_dir, cam_pos, lights, atlas, tile_dim, descrip
     s.active_lights = active_lights
     s.no_bias = no_bias
     s.stepping_mode = stepping_mode
+    s.coarse_log2 = coarse_log2
     tr = np.asarray(trig, dtype=np.float32) if trig is not None else camera_trig(np.asarray(cam_dir, dtype=np.float32))
     s.cam_trig = (C.c_float * 4)(*[float(v) for v in tr])
     image = np.zeros((height, width, 4), dtype=np.float32)

@@ -370,6 +370,7 @@ typedef struct {
     uint64_t idx[ORC_MAX_DEPTH];
     int32_t  pv[3];
     uint32_t reads;
+    int      coarse_level;            /* mode B with the coarse table (0: none): see svo_locate */
 } svo_cursor;
 
 static void svo_init(svo_cursor *c, const desc_src *descriptors, uint64_t root_index, int dim) {
@@ -381,12 +382,30 @@ static void svo_init(svo_cursor *c, const desc_src *descriptors, uint64_t root_i
     c->desc[0] = desc_at(descriptors, root_index);
     c->pv[0] = c->pv[1] = c->pv[2] = 0;
     c->reads = 1;
+    c->coarse_level = 0;
 }
 
 /* returns 1 when voxel v is solid (valid & leaf), 0 when it lies in an empty node */
-static int svo_locate(svo_cursor *c, const int32_t v[3]) {
+static int svo_locate_from(svo_cursor *c, const int32_t v[3], int table);
+static int svo_locate(svo_cursor *c, const int32_t v[3]) { return svo_locate_from(c, v, 0); }
+
+/* table != 0 (mode B, after a jump): when the voxel lies in another cell of the level-L grid (L = coarse_level) than the voxel
+ * located last, the product reads the cursor state of the new cell from a dense table -- ONE 8-byte read that stands for
+ * the descent from the root to level L, or to the node above it whose child toward the cell is empty or a leaf
+ * (raycast_jump_kernel.hip table_block / coarse_build_kernel) -- and goes on below as usual.  Restated here without a table:
+ * the same descent, its reads not counted, one read for the table entry.  The nodes found and every result are those of
+ * the canonical traversal; only `reads` differs.                                                                          */
+static int svo_locate_from(svo_cursor *c, const int32_t v[3], int table) {
     uint32_t diff = (uint32_t)((v[0] ^ c->pv[0]) | (v[1] ^ c->pv[1]) | (v[2] ^ c->pv[2]));
-    while (c->top > 0 && (diff >> (c->n - c->top)) != 0) c->top--;
+    const int L = table ? c->coarse_level : 0;
+    int free_until = 0;               /* descents into levels <= free_until are the table's */
+    if (L > 0 && (diff >> (c->n - L)) != 0) {
+        c->top = 0;
+        c->reads++;
+        free_until = L;
+    } else {
+        while (c->top > 0 && (diff >> (c->n - c->top)) != 0) c->top--;
+    }
     c->pv[0] = v[0]; c->pv[1] = v[1]; c->pv[2] = v[2];
     for (;;) {
         int b = c->n - c->top - 1;
@@ -405,7 +424,7 @@ static int svo_locate(svo_cursor *c, const int32_t v[3]) {
         c->top++;
         c->idx[c->top] = child;
         c->desc[c->top] = desc_at(&c->descriptors, child);
-        c->reads++;
+        if (c->top > free_until) c->reads++;
     }
 }
 
@@ -612,6 +631,12 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
     if (svo) {
         const desc_src src = scene_src(s);
         svo_init(&cur, &src, (uint64_t)s->octree_root_index, (int)s->octree_dimensions);
+        if (jump) {                                   /* the product's rule (vrc_params.h coarse_level_for_depth), restated */
+            int L = s->coarse_log2 < 0 ? (cur.n >= 5 ? (cur.n - 2 < 9 ? cur.n - 2 : 9) : 0) : s->coarse_log2;
+            if (L > cur.n - 2) L = cur.n - 2;
+            if (L > 10) L = 10;
+            cur.coarse_level = (L >= 1 && s->n_descriptors < (1ULL << 43)) ? L : 0;
+        }
         /* the per-pixel get_oct_vox(camera voxel) of the reference == the
          * cursor's first descent (only meaningful when the camera is inside
          * the map; otherwise only the root read is charged)                  */
@@ -671,7 +696,7 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
             break;
         }
         if (svo) {
-            voxel_data = svo_locate(&cur, voxel) ? 5 : 0;
+            voxel_data = svo_locate_from(&cur, voxel, jump) ? 5 : 0;
             if (jump) {
                 if (voxel_data) jump_hit_intersection(&js, vstep, voxel, face_mask, t_exit, delta_t, it);
                 jump_set_node(&js, voxel, voxel_data ? 1 : 1 << (cur.n - cur.top - 1));

@@ -132,6 +132,9 @@ typedef struct {
     float           cam_trig[4];         /* sin(dir.x) cos(dir.x) sin(dir.y) cos(dir.y) */
     int32_t         stepping_mode;       /* 0: the reference's per-voxel DDA (:558-560).  1: "mode B" (SURVEY D1), SVO only:
                                             stateless node-exit jumps, see raycast_pixel / jump_step in vrc_oracle.c   */
+    int32_t         coarse_log2;         /* mode B only (round 4): the levels above this one are a dense table in the product
+                                            (raycast_jump_kernel.hip coarse_build_kernel); -1: by depth (n >= 5: min(n - 2, 9),
+                                            else none), 0: none.  Changes the descriptor-read count only, see svo_locate     */
     /* optional paged descriptor source (see ORC_PAGE_SIZE): when desc_page_fetch is set, `descriptors` is not read;
      * desc_pages is a zero-initialised table of ceil(n_descriptors / ORC_PAGE_SIZE) pointers the oracle fills */
     const uint64_t  **desc_pages;

@@ -25,8 +25,47 @@ __device__ __forceinline__ uint64_t jump_make_entry(const uint64_t *__restrict__
     if (d & 0x8000ULL) base = descriptors[base];          // far pointer: slot holds an absolute index
     return (base << 16) | ((d >> 16) & 0xffffULL);
 }
-enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4 };
+enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4, jTable = 5 };
+
+// index of cell (cx, cy, cz) of the coarse table with 2^lc cells per axis: bricks of (2^kCoarseBrickLog2)^3 cells are contiguous,
+// bricks in x-fastest order -- the rays of a tile land in a patch of neighbouring cells, whatever plane that patch lies in
+// (measured, headline frame, table levels 8 / 9 / 10: plain x-fastest order 0.639 / 0.581 / 0.555 ms, bricks of 2^3, 4^3, 8^3 cells
+// 0.666 / 0.602 / 0.563-0.573: the index arithmetic costs more than the locality gives -- the default is no bricks)
+#ifndef VRC_COARSE_BRICK
+#define VRC_COARSE_BRICK 0
+#endif
+constexpr int kCoarseBrickLog2 = VRC_COARSE_BRICK;
+__device__ __forceinline__ uint64_t coarse_index(unsigned cx, unsigned cy, unsigned cz, int lc) {
+    constexpr unsigned k = kCoarseBrickLog2, m = (1u << k) - 1u;
+    if (k == 0 || lc < (int)k) return (uint64_t)cx | ((uint64_t)cy << lc) | ((uint64_t)cz << (2 * lc));
+    const int lb = lc - (int)k;                            // bricks per axis = 2^lb
+    const uint64_t brick = (uint64_t)(cx >> k) | ((uint64_t)(cy >> k) << lb) | ((uint64_t)(cz >> k) << (2 * lb));
+    return (brick << (3 * k)) | (cx & m) | ((cy & m) << k) | ((cz & m) << (2 * k));
+}
 }  // namespace
+
+// Coarse table (round 4): one thread per cell walks the canonical descent from the root toward the cell and stores the
+// cursor state it ends with -- the node at level `lc`, or the node above whose child toward the cell is empty or a leaf.
+__global__ void coarse_build_kernel(const uint64_t *__restrict__ descriptors, uint64_t root_index, int n, int lc, uint64_t *__restrict__ out) {
+    const uint64_t cell = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;     // cells in x-fastest order; stored at coarse_index()
+    if (cell >> (3 * lc)) return;
+    const int sh = n - lc;
+    const unsigned ccx = (unsigned)(cell & ((1u << lc) - 1u)), ccy = (unsigned)((cell >> lc) & ((1u << lc) - 1u)), ccz = (unsigned)(cell >> (2 * lc));
+    const int x = (int)(ccx << sh), y = (int)(ccy << sh), z = (int)(ccz << sh);
+    const uint64_t idx = coarse_index(ccx, ccy, ccz, lc);
+    uint64_t cur = jump_make_entry(descriptors, root_index, descriptors[root_index]);
+    int top = 0;
+    while (top < lc) {
+        const int b = n - top - 1;
+        const int i = ((x >> b) & 1) | (((y >> b) & 1) << 1) | (((z >> b) & 1) << 2);
+        const unsigned masks = (unsigned)cur & 0xffffu, bit = 1u << i;
+        if (!(masks & bit) || ((masks >> 8) & bit)) break;    // empty or leaf: the descent block's test finds it from here
+        const uint64_t child = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
+        cur = jump_make_entry(descriptors, child, descriptors[child]);
+        top++;
+    }
+    out[idx] = cur | ((uint64_t)top << kCoarseLevelShift);
+}
 
 // blocks per CU the register budget is set for: 8 waves per SIMD (64 VGPRs, 14 dwords of scratch) measured fastest --
 // 5 / 6 / 7 blocks: 0.93 / 0.91 / 0.85 ms on the headline frame with the first version of the kernel, 7 / 8 blocks
@@ -52,6 +91,11 @@ enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4 };
 #ifndef VRC_ROUND_PROGRAM
 #define VRC_ROUND_PROGRAM VRC_J(true) VRC_D(true) VRC_D(true) VRC_J(true) VRC_D(true) VRC_D(true)
 #endif
+// ... and with the coarse table (VRC_T = the table block: one 8-byte load + the descent block's test, for the lanes whose jump
+// left their level-lc cell)
+#ifndef VRC_ROUND_PROGRAM_COARSE
+#define VRC_ROUND_PROGRAM_COARSE VRC_J(true) VRC_T(true) VRC_D(false) VRC_J(true) VRC_T(true) VRC_D(false)
+#endif
 #ifndef VRC_JUMP_SHADE_THRESHOLD
 // lanes that must wait for the hit block before a wave with stepping lanes runs it: 8 / 16 / 32 / 48 / 64 measured
 // 0.83 / 0.81 / 0.78 / 0.80 / 0.665 ms (64 = only when no lane of the wave has anything cheaper to do); with the
@@ -64,7 +108,9 @@ enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4 };
 #define VRC_JUMP_MIN_BLOCKS (32 / VRC_TILES_PER_BLOCK)
 #endif
 
-template <bool kMulti>
+// kCoarse: the levels above coarse_log2 are a dense table (RaycastParams::coarse): a jump that leaves its level-lc cell reads
+//          the cursor state for the new cell with ONE load instead of popping the stack and descending level by level
+template <bool kMulti, bool kCoarse>
 __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_jump_kernel(const RaycastParams p) {
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-2
     // the counter partials of the block reuse the stack's memory once every ray of the block has ended (no static LDS:
@@ -88,6 +134,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
     float t_exit = 0.0f;
 
     const int n = p.log2_dim;
+    const int lc = kCoarse ? p.coarse_log2 : 0, csh = n - lc;            // table level, log2 of the cell size
     const uint64_t *__restrict__ descriptors = p.descriptors;
     // the root's entry is the same for every ray of the frame: it lives in scalar registers
     uint64_t root_entry;
@@ -222,22 +269,21 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
                         // pop to the deepest level whose node holds both the voxel located last and the new one (after a
                         // redirect the two are not neighbours: the cursor still sits at the hit voxel)
                         const unsigned diff = (unsigned)((nx ^ pvx) | (ny ^ pvy) | (nz ^ pvz));
-                        if (top > 0 && (diff >> (n - top)) != 0) {
-                            top = n - (31 - __clz((int)diff)) - 1;
-                            cur = (top == 0) ? root_entry : lds_stack[(top - 1) * kBlockThreads + tid];
-                        }
                         pvx = nx; pvy = ny; pvz = nz;
-                        mode = jDescend;
+                        if (kCoarse && (diff >> csh) != 0) {
+                            mode = jTable;                    // another level-lc cell: the cursor comes from the table
+                        } else {
+                            if (top > 0 && (diff >> (n - top)) != 0) {
+                                top = n - (31 - __clz((int)diff)) - 1;       // (>= lc with the table: the voxels share a cell)
+                                cur = (top == 0) ? root_entry : lds_stack[(top - 1) * kBlockThreads + tid];
+                            }
+                            mode = jDescend;
+                        }
                     }
                 }
             }
         };
-        auto descend_block = [&]() {
-#ifdef VRC_SCHED_STATS
-        if ((tid & 63) == 0) s_dwaves++;
-        s_dlanes += mode == jDescend;
-#endif
-        if (mode == jDescend) {
+        auto descend_body = [&]() {
                 const int b = n - top - 1;
                 const int i = ((r.vx >> b) & 1) | (((r.vy >> b) & 1) << 1) | (((r.vz >> b) & 1) << 2);
                 const unsigned masks = (unsigned)cur & 0xffffu;
@@ -263,15 +309,36 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
                     if (top < n - 2) lds_stack[top * kBlockThreads + tid] = cur;     // the deepest entry is never popped to
                     top++;
                 }
+        };
+        auto descend_block = [&]() {
+#ifdef VRC_SCHED_STATS
+        if ((tid & 63) == 0) s_dwaves++;
+        s_dlanes += mode == jDescend;
+#endif
+        if (mode == jDescend) descend_body();
+        };
+        // the table block: the cursor state of the cell the ray landed in (one 8-byte load, counted like a descriptor read),
+        // then the descent block's test right away -- in the coarse empty space above the terrain that test ends the event
+        auto table_block = [&]() {
+        if (kCoarse && mode == jTable) {
+                const uint64_t e = p.coarse[coarse_index((unsigned)(r.vx >> csh), (unsigned)(r.vy >> csh), (unsigned)(r.vz >> csh), lc)];
+                c_desc++;
+                cur = e & ((1ULL << kCoarseLevelShift) - 1ULL);
+                top = (int)(e >> kCoarseLevelShift);
+                if (top == lc) lds_stack[(lc - 1) * kBlockThreads + tid] = cur;      // pops inside the cell end here (lc <= n - 2)
+                mode = jDescend;
+                descend_body();
             }
         };
         // later blocks of the round run only if some lane of the wave waits for them (a wave-uniform branch)
 #define VRC_J(always) if ((always) || __ballot(mode == jStep) != 0ULL) jump_block();
 #define VRC_D(always) if ((always) || __ballot(mode == jDescend) != 0ULL) descend_block();
-        VRC_ROUND_PROGRAM
+#define VRC_T(always) if ((always) || __ballot(mode == jTable) != 0ULL) table_block();
+        if (kCoarse) { VRC_ROUND_PROGRAM_COARSE } else { VRC_ROUND_PROGRAM }
 #undef VRC_J
 #undef VRC_D
-        const unsigned long long st = __ballot(mode == jStep || mode == jDescend);
+#undef VRC_T
+        const unsigned long long st = __ballot(mode == jStep || mode == jDescend || mode == jTable);
         const unsigned long long sh = __ballot(mode == jShade || (kMulti && mode == jRelight));
         if ((st | sh) == 0ULL || --rounds_left < 0) break;
 
@@ -342,8 +409,22 @@ hipError_t launch_raycast_jump(const RaycastParams &p, hipStream_t stream) {
     if (nblocks <= 0) return hipSuccess;
     const int levels = p.log2_dim > 2 ? p.log2_dim - 2 : 1;     // >= the counter partials that reuse the memory
     const size_t lds = (size_t)levels * kBlockThreads * sizeof(uint64_t);
-    if (p.light_count > 1) hipLaunchKernelGGL((raycast_jump_kernel<true>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
-    else hipLaunchKernelGGL((raycast_jump_kernel<false>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+    const bool coarse = p.coarse != nullptr && p.coarse_log2 >= 1 && p.coarse_log2 <= p.log2_dim - 2;
+    if (coarse) {
+        if (p.light_count > 1) hipLaunchKernelGGL((raycast_jump_kernel<true, true>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+        else hipLaunchKernelGGL((raycast_jump_kernel<false, true>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+    } else {
+        if (p.light_count > 1) hipLaunchKernelGGL((raycast_jump_kernel<true, false>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+        else hipLaunchKernelGGL((raycast_jump_kernel<false, false>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p);
+    }
+    return hipGetLastError();
+}
+
+// the coarse table of a tree: 2^(3 lc) entries at `out` (device memory)
+hipError_t launch_coarse_build(const uint64_t *descriptors, uint64_t root_index, int log2_dim, int lc, uint64_t *out, hipStream_t stream) {
+    (void)hipGetLastError();
+    const uint64_t cells = 1ULL << (3 * lc);
+    hipLaunchKernelGGL(coarse_build_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, descriptors, root_index, log2_dim, lc, out);
     return hipGetLastError();
 }
 

@@ -26,6 +26,7 @@
 namespace vrc {
 hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream);
 bool jump_tables_in_lds(const RaycastParams &p);
+hipError_t launch_coarse_build(const uint64_t *descriptors, uint64_t root_index, int log2_dim, int lc, uint64_t *out, hipStream_t stream);
 hipError_t launch_frame_setup(const RaycastParams &p, hipStream_t stream);
 hipError_t launch_reduce_counters(const unsigned long long *partials, int nblocks, unsigned long long *out,
                                   hipStream_t stream);
@@ -53,6 +54,8 @@ struct vrc_caster {
     // scene buffers (device)
     int8_t *d_map = nullptr; int32_t map_dim[3] = {0, 0, 0};
     uint64_t *d_desc = nullptr; uint64_t n_desc = 0; bool have_octree = false;
+    // mode B's coarse table of the tree (vrc_params.h RaycastParams::coarse), built on first use: valid for (root, depth, level)
+    uint64_t *d_coarse = nullptr; uint64_t coarse_root = 0; int coarse_depth = 0, coarse_log2 = 0;
     bool owns_desc = true;                // false: a group rank on the same GPU as rank 0 shares rank 0's arrays
     bool own_copy = false;                // group flag VRC_GROUP_OWN_COPIES: never share, always take the device-to-device copy path
     int32_t peer_access = -1;             // -1 same GPU as rank 0 / rank 0 itself, 1 direct peer access enabled, 0 the runtime stages the copies
@@ -130,6 +133,7 @@ void release(T *&p) {
 }
 
 void release_tree(vrc_caster *h) {
+    release(h->d_coarse); h->coarse_log2 = 0;                      // the table describes the tree that goes away
     if (h->owns_desc) { release(h->d_desc); release(h->d_attach_lookup); release(h->d_attach); }
     h->d_desc = nullptr; h->d_attach_lookup = nullptr; h->d_attach = nullptr;
     h->owns_desc = true;
@@ -1004,6 +1008,23 @@ int compute_async_one(vrc_caster *h) {
         p.jump_cache = h->d_jump_cache; p.jump_slots = h->d_jump_slots; p.jump_slot_count = h->jump_slot_count;
     }
     h->last_blocks = nblocks;
+    if (svo && p.stepping_mode == 1) {
+        // mode B: the levels above coarse_log2 as a dense table (setting coarse_log2: -1 = by depth, 0 = none); built here on
+        // first use and whenever the tree, its root or its depth changed
+        int64_t lc = setting_or(h, "coarse_log2", -1);
+        if (lc < 0) lc = vrc::coarse_level_for_depth(p.log2_dim);
+        lc = std::min<int64_t>(lc, std::min(p.log2_dim - 2, 10));
+        if (lc >= 1 && h->n_desc < (1ULL << 43)) {
+            if (!h->d_coarse || h->coarse_log2 != (int)lc || h->coarse_root != p.root_index || h->coarse_depth != p.log2_dim) {
+                release(h->d_coarse);
+                h->coarse_log2 = 0;
+                HIP_TRY(h, hipMalloc((void **)&h->d_coarse, sizeof(uint64_t) << (3 * lc)));
+                HIP_TRY(h, vrc::launch_coarse_build(h->d_desc, p.root_index, p.log2_dim, (int)lc, h->d_coarse, h->stream));
+                h->coarse_log2 = (int)lc; h->coarse_root = p.root_index; h->coarse_depth = p.log2_dim;
+            }
+            p.coarse = h->d_coarse; p.coarse_log2 = (int32_t)lc;
+        }
+    }
     h->frames_enqueued++;
 
     vrc_caster::EvPair ev;

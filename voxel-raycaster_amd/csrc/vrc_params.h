@@ -39,6 +39,13 @@ constexpr int kJumpSlotsPerXcd = 256;         // table slots per XCD: 32 CUs x 8
 constexpr int kJumpSlots = 8 * kJumpSlotsPerXcd;   // a block takes a slot of ITS XCD while it runs (the L2s of two XCDs are not coherent)
 constexpr int kMaxLights = 8;         // light slots (include/LightController.h:95)
 constexpr int kMaxLevels = 24;        // descriptor levels the LDS stack can hold (dim <= 2^24)
+// mode B's coarse table: by default 512^3 cells at most (1 GB; the headline frame: 0.695 ms without a table, levels 5 .. 10:
+// 0.756 / 0.727 / 0.688 / 0.635 / 0.574 / 0.550 ms -- level 10 is an 8 GB table for a 161 MB tree and stays a setting), and
+// never finer than cells of 4 voxels (the bottom two levels are always descriptors)
+constexpr int kCoarseMaxLog2 = 9;
+constexpr int kCoarseLevelShift = 59; // entry bits 59-63: level; child indices must stay below 2^43
+// the table level for a tree of depth n (0: no table)
+constexpr int coarse_level_for_depth(int n) { return n >= 5 ? (n - 2 < kCoarseMaxLog2 ? n - 2 : kCoarseMaxLog2) : 0; }
 
 // hit-record flag bits (include/vrc.h VRC_HIT_FLAG_*)
 constexpr int kFlagWritten = 1, kFlagShadowCast = 2, kFlagShadowHit = 4, kFlagOob = 8;
@@ -106,6 +113,11 @@ struct RaycastParams {
     // rank's rows; 0: full-frame buffers indexed by the image row
     int32_t row_sliced;
     int32_t stepping_mode;            // 0: exact per-voxel DDA (reference parity); 1: node-exit jumps (SURVEY D1 mode B)
+    // mode B only: the top of the tree as a dense grid of 2^coarse_log2 cells per axis (x fastest).  An entry is the state the
+    // canonical descent toward the cell has when it reaches level coarse_log2 or meets an empty / leaf child before:
+    // bits 0-15 leaf << 8 | valid, 16-58 absolute index of the first kept child, 59-63 the level of that node.  nullptr: no table
+    const uint64_t *coarse;
+    int32_t coarse_log2;
     unsigned long long *counters;
     // host-mapped flag the round watchdog raises (checked by vrc_sync: a truncated frame never looks like success)
     unsigned int *watchdog_flag;
