@@ -36,6 +36,9 @@
 #include "raycast_common.hpp"
 #include "safe_run.hpp"
 
+#ifndef VRC_LDS_RING
+#define VRC_LDS_RING 4                // rows of the Euclid-table ring when it lives in LDS (exact_jump.hpp: 3 or 4; with the coarse table the stack is 3 levels and 4 rows fit: 2.30 -> 2.29 ms)
+#endif
 #ifndef VRC_RELIGHT_THRESHOLD
 #define VRC_RELIGHT_THRESHOLD 64      // lanes that must wait for the next light before a wave with stepping lanes serves them
 #endif
@@ -152,10 +155,16 @@ constexpr int kHwRegXccId = (3 << 11) | (0 << 6) | 20;
 //         instead of in the global table buffer -- chosen by the launch when stack + tables of 5 blocks fit the CU's LDS
 //         (depth <= 12): no slot to take, 12 bytes less scratch, 2.57 -> 2.51 ms on the headline frame; deeper trees keep the
 //         global tables (with the rows in LDS they would run at 4 blocks per CU: depth 13 3.36 -> 3.56 ms, depth 16 6.85 -> 7.42)
-template <bool kJump, bool kMulti, bool kTuned, bool kLdsTab = false>
+// kCoarse: the levels above p.coarse_log2 are read from the dense table of the tree's top (RaycastParams::coarse, built by
+//         raycast_jump_kernel.hip coarse_build_kernel): a voxel in another level-lc cell than the voxel located last costs ONE
+//         load instead of a pop and a level-by-level descent with a dependent load each.  The descriptor-read COUNT stays the
+//         canonical one of SURVEY 8d (the descents the table stands for are counted by their number: level found - level of
+//         the common ancestor), so counters and hit records are those of the plain traversal, bit for bit.  The LDS stack
+//         then only holds the levels from lc down (slot = level - lc).
+template <bool kJump, bool kMulti, bool kTuned, bool kLdsTab = false, bool kCoarse = false>
 __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
     static_assert(kJump || !kLdsTab, "tables exist for the jump instances only");
-    extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1
+    extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1  (kCoarse: [level-lc][thread], levels lc..n-1)
     __shared__ unsigned long long block_ctr[kCtrCount];
     __shared__ int s_jump_slot;
     const int tid = threadIdx.x;
@@ -212,11 +221,23 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     int top = 0, pvx = 0, pvy = 0, pvz = 0;
 
     // returns b >= 0: voxel lies in an empty node of size 2^b;  -1: voxel is solid
+    const int lc = kCoarse ? p.coarse_log2 : 0, csh = n - lc;           // table level, log2 of its cell size
+    const int sbase = kCoarse ? lc : 1;                   // level of stack slot 0
     auto locate = [&](int x, int y, int z) -> int {
         const unsigned diff = (unsigned)((x ^ pvx) | (y ^ pvy) | (z ^ pvz));
-        if (top > 0 && (diff >> (n - top)) != 0) {
+        if (kCoarse && (top < lc || (diff >> csh) != 0)) {
+            // the cursor of the new cell comes from the table; the canonical traversal would have popped to level a (the deepest
+            // node that holds both voxels, or where the cursor already sits) and made t - a descents from there
+            int a = n - (32 - __clz((int)diff));          // (diff == 0: n)
+            a = a < top ? a : top;
+            const uint64_t e = p.coarse[(uint64_t)(unsigned)(x >> csh) | ((uint64_t)(unsigned)(y >> csh) << lc) | ((uint64_t)(unsigned)(z >> csh) << (2 * lc))];
+            cur = e & ((1ULL << kCoarseLevelShift) - 1ULL);
+            top = (int)(e >> kCoarseLevelShift);
+            c_desc += (unsigned)(top - a);
+            if (top == lc) lds_stack[tid] = cur;          // slot 0 = level lc: pops inside the cell end here
+        } else if (top > 0 && (diff >> (n - top)) != 0) {
             top = n - (31 - __clz((int)diff)) - 1;        // deepest level whose node holds both voxels
-            cur = (top == 0) ? root_entry : lds_stack[(top - 1) * kBlockThreads + tid];
+            cur = (!kCoarse && top == 0) ? root_entry : lds_stack[(top - sbase) * kBlockThreads + tid];
         }
         pvx = x; pvy = y; pvz = z;
         for (;;) {
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             const uint64_t d = descriptors[child];
             c_desc++;
             cur = make_entry(descriptors, child, d);
-            lds_stack[top * kBlockThreads + tid] = cur;   // level top+1 lives in slot top
+            lds_stack[(top + 1 - sbase) * kBlockThreads + tid] = cur;   // level top+1 (>= lc + 1 with the table)
             top++;
         }
     };
@@ -239,7 +260,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         if (!p.attach_lookup || top != n - 1) return 5;   // only bottom-level descriptors carry materials
         uint64_t node = p.root_index;
         if (top > 0) {
-            const uint64_t parent = (top == 1) ? root_entry : lds_stack[(top - 2) * kBlockThreads + tid];
+            const uint64_t parent = (!kCoarse && top == 1) ? root_entry : lds_stack[(top - 1 - sbase) * kBlockThreads + tid];
             const int slot = ((x >> 1) & 1) | (((y >> 1) & 1) << 1) | (((z >> 1) & 1) << 2);
             node = (parent >> 16) + (uint64_t)(__popc((unsigned)parent & 0xffu & ((2u << slot) - 1u)) - 1);
         }
@@ -291,9 +312,9 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     uint32_t *jtab = nullptr;
     uint32_t jrows = 0;
     // rows in LDS: behind the traversal stack, [ring row][pair][thread], one dword each (consecutive threads, consecutive banks)
-    constexpr int kRing = kLdsTab ? 3 : 4;               // table rows per ray (exact_jump.hpp)
+    constexpr int kRing = kLdsTab ? VRC_LDS_RING : 4;    // table rows per ray (exact_jump.hpp)
     const int jstride = kLdsTab ? kBlockThreads : 64;
-    if (kLdsTab) jtab = reinterpret_cast<uint32_t *>(lds_stack + (size_t)(p.log2_dim > 1 ? p.log2_dim - 1 : 1) * kBlockThreads) + tid;
+    if (kLdsTab) jtab = reinterpret_cast<uint32_t *>(lds_stack + (size_t)(kCoarse ? n - lc : (n > 1 ? n - 1 : 1)) * kBlockThreads) + tid;
     else if (kJump && s_jump_slot >= 0) jtab = p.jump_cache + ((size_t)s_jump_slot * kTilesPerBlock + (tid >> 6)) * (size_t)(3 * kRing * 64) + (tid & 63);
 
     if (in_image) {
@@ -859,11 +880,14 @@ hipError_t launch_frame_setup(const RaycastParams &p, hipStream_t stream) {
 hipError_t launch_raycast_jump(const RaycastParams &p, hipStream_t stream);   // raycast_jump_kernel.hip
 
 // dynamic LDS of the SVO kernel: the traversal stack, and behind it the jump tables when they live in LDS
+static bool svo_uses_coarse(const RaycastParams &p) {
+    return p.coarse != nullptr && p.coarse_log2 >= 1 && p.coarse_log2 <= p.log2_dim - 2;
+}
 static size_t svo_stack_bytes(const RaycastParams &p) {
-    const int levels = p.log2_dim > 1 ? p.log2_dim - 1 : 1;
+    const int levels = svo_uses_coarse(p) ? p.log2_dim - p.coarse_log2 : (p.log2_dim > 1 ? p.log2_dim - 1 : 1);
     return (size_t)levels * kBlockThreads * sizeof(uint64_t) + (size_t)p.lds_pad_bytes;
 }
-constexpr size_t kLdsTabBytes = (size_t)(3 * 3) * kBlockThreads * sizeof(uint32_t);   // 3 ring rows x 3 pairs, one dword per thread
+constexpr size_t kLdsTabBytes = (size_t)(3 * VRC_LDS_RING) * kBlockThreads * sizeof(uint32_t);   // ring rows x 3 pairs, one dword per thread
 
 // Do the Euclid tables of this frame live in LDS?  Yes when the jump instance with stack + tables still reaches the blocks
 // per CU its registers allow (VRC_MIN_BLOCKS_JUMP) -- asked of the runtime once per LDS size; setting jump_tables_lds = 0 / 1
@@ -877,7 +901,7 @@ bool jump_tables_in_lds(const RaycastParams &p) {
     static bool cached = false;
     if (cached_lds != lds) {
         int per_cu = 0;
-        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true>),
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, true>),
                                                                           kBlockThreads, lds);
         (void)hipGetLastError();
         cached = e == hipSuccess && per_cu >= VRC_MIN_BLOCKS_JUMP;
@@ -901,22 +925,18 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
                            p.exact_steps == kDefaultExactSteps && p.burst_steps == kDefaultBurstSteps;
         if (jump && !lds_tab && (!p.jump_cache || !p.jump_slots || p.jump_slot_count < 1)) return hipErrorInvalidValue;
 #define VRC_LAUNCH(...) hipLaunchKernelGGL((raycast_svo_kernel<__VA_ARGS__>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p)
-        if (lds_tab) {
-            if (multi && tuned) VRC_LAUNCH(true, true, true, true);
-            else if (multi) VRC_LAUNCH(true, true, false, true);
-            else if (tuned) VRC_LAUNCH(true, false, true, true);
-            else VRC_LAUNCH(true, false, false, true);
-        } else if (jump) {
-            if (multi && tuned) VRC_LAUNCH(true, true, true);
-            else if (multi) VRC_LAUNCH(true, true, false);
-            else if (tuned) VRC_LAUNCH(true, false, true);
-            else VRC_LAUNCH(true, false, false);
+#define VRC_LAUNCH_MT(J, L, C) do { if (multi && tuned) VRC_LAUNCH(J, true, true, L, C); else if (multi) VRC_LAUNCH(J, true, false, L, C); \
+                                    else if (tuned) VRC_LAUNCH(J, false, true, L, C); else VRC_LAUNCH(J, false, false, L, C); } while (0)
+        if (svo_uses_coarse(p)) {
+            if (lds_tab) VRC_LAUNCH_MT(true, true, true);
+            else if (jump) VRC_LAUNCH_MT(true, false, true);
+            else VRC_LAUNCH_MT(false, false, true);
         } else {
-            if (multi && tuned) VRC_LAUNCH(false, true, true);
-            else if (multi) VRC_LAUNCH(false, true, false);
-            else if (tuned) VRC_LAUNCH(false, false, true);
-            else VRC_LAUNCH(false, false, false);
+            if (lds_tab) VRC_LAUNCH_MT(true, true, false);
+            else if (jump) VRC_LAUNCH_MT(true, false, false);
+            else VRC_LAUNCH_MT(false, false, false);
         }
+#undef VRC_LAUNCH_MT
 #undef VRC_LAUNCH
     } else {
         hipLaunchKernelGGL(raycast_array_kernel, dim3(nblocks), dim3(kBlockThreads), 0, stream, p);

@@ -995,22 +995,9 @@ int compute_async_one(vrc_caster *h) {
         h->partial_blocks = nblocks;
     }
     p.counters = h->d_partials;
-    // exact closed-form jumps: on from depth 12; the threshold depends on where the Euclid tables live (LDS when stack + tables
-    // fit at full occupancy: depth 12)
-    p.jump_tables_lds = (int32_t)std::min<int64_t>(2, std::max<int64_t>(0, setting_or(h, "jump_tables_lds", 2)));
-    const bool tables_in_lds = vrc::jump_tables_in_lds(p);
-    p.jump_min_run = (int32_t)std::min<int64_t>(vrc::kJumpOff, std::max<int64_t>(1, setting_or(h, "jump_min_run",
-                                    p.log2_dim >= vrc::kDefaultJumpMinDepth ? (tables_in_lds ? vrc::kDefaultJumpMinRunLds : vrc::kDefaultJumpMinRun)
-                                                                            : vrc::kJumpOff)));
-    if (svo && p.stepping_mode == 0 && p.jump_min_run < vrc::kJumpOff && !tables_in_lds) {
-        const int rc = ensure_jump_cache(h, nblocks);
-        if (rc != VRC_OK) return rc;
-        p.jump_cache = h->d_jump_cache; p.jump_slots = h->d_jump_slots; p.jump_slot_count = h->jump_slot_count;
-    }
-    h->last_blocks = nblocks;
-    if (svo && p.stepping_mode == 1) {
-        // mode B: the levels above coarse_log2 as a dense table (setting coarse_log2: -1 = by depth, 0 = none); built here on
-        // first use and whenever the tree, its root or its depth changed
+    if (svo) {
+        // the levels above coarse_log2 as a dense table (setting coarse_log2: -1 = by depth, 0 = none), read by both SVO kernels;
+        // built here on first use and whenever the tree, its root or its depth changed
         int64_t lc = setting_or(h, "coarse_log2", -1);
         if (lc < 0) lc = vrc::coarse_level_for_depth(p.log2_dim);
         lc = std::min<int64_t>(lc, std::min(p.log2_dim - 2, 10));
@@ -1025,6 +1012,19 @@ int compute_async_one(vrc_caster *h) {
             p.coarse = h->d_coarse; p.coarse_log2 = (int32_t)lc;
         }
     }
+    // exact closed-form jumps: on from depth 12; the threshold depends on where the Euclid tables live (LDS when stack + tables
+    // fit at full occupancy: depth 12)
+    p.jump_tables_lds = (int32_t)std::min<int64_t>(2, std::max<int64_t>(0, setting_or(h, "jump_tables_lds", 2)));
+    const bool tables_in_lds = vrc::jump_tables_in_lds(p);
+    p.jump_min_run = (int32_t)std::min<int64_t>(vrc::kJumpOff, std::max<int64_t>(1, setting_or(h, "jump_min_run",
+                                    p.log2_dim >= vrc::kDefaultJumpMinDepth ? (tables_in_lds ? vrc::kDefaultJumpMinRunLds : vrc::kDefaultJumpMinRun)
+                                                                            : vrc::kJumpOff)));
+    if (svo && p.stepping_mode == 0 && p.jump_min_run < vrc::kJumpOff && !tables_in_lds) {
+        const int rc = ensure_jump_cache(h, nblocks);
+        if (rc != VRC_OK) return rc;
+        p.jump_cache = h->d_jump_cache; p.jump_slots = h->d_jump_slots; p.jump_slot_count = h->jump_slot_count;
+    }
+    h->last_blocks = nblocks;
     h->frames_enqueued++;
 
     vrc_caster::EvPair ev;
