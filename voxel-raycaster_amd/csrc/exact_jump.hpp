@@ -142,12 +142,10 @@ VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
 //   row = e - kJumpFirstBinade (0 <= row < kJumpBinades), pairs xy, xz, yz:   tab[(3 * (row % kJumpRing) + pair) * stride]
 // A ray's intersection_t only grow, so it needs the row of the binade it is in and those ahead: the table is a ring of
 // kJumpRing rows, and `rows` (a bit per row, kept by the caller) says which rows it holds right now.
-//   bits 0-23  s: s * inc_a == g (mod inc_b), 0 <= s < inc_b        bits 24-31  g = gcd(inc_a, inc_b)
-//   g == 255: the gcd is 255 or more and the pair is solved afresh when it is needed (0.4 % of the pairs; with the full gcd
-//   in a second dword those on-the-spot runs disappear, but the wider rows cost as much as they save: 2.54-2.57 ms either
-//   way, 88 instead of 72 bytes of scratch, 1.0 instead of 0.67 GB of HBM traffic per frame.  Round 4: s is only needed modulo
-//   inc_b / g, so s and g always fit one dword with a variable split (5 bits of length, then g, then s): no on-the-spot runs
-//   left, bit-identical, and 4 % SLOWER -- 2.67 vs 2.57 ms -- dropped);  whole dword 0: no entry
+//   s and g = gcd(inc_a, inc_b) with s * inc_a == g (mod inc_b), 0 <= s < inc_b, packed by jump_entry_pack (two formats, see
+//   there);  whole dword 0: no entry.  (History: a second dword for the full gcd cost as much as it saved -- 88 instead of 72
+//   bytes of scratch, 1.0 instead of 0.67 GB of traffic; one variable-split format for every pair was 4 % slower with the tables
+//   in global memory: its decode sat on the hot path.)
 // The increments depend on (delta_t, binade) only.  In HBM (RaycastParams::jump_cache), one table per lane, interleaved
 // over the 64 lanes of a wave (stride 64) so that a row is one coalesced 256-byte line.
 // ---------------------------------------------------------------------------------------------------------------
@@ -155,7 +153,7 @@ VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
 #define VRC_JUMP_FIRST_LOG2 7
 #endif
 constexpr int kJumpFirstBinade = 127 + VRC_JUMP_FIRST_LOG2;   // no table below t = 128: a binade of fewer voxels than a Euclid run costs
-constexpr int kJumpBinades = 12;              // t < 2^19
+constexpr int kJumpBinades = 19 - VRC_JUMP_FIRST_LOG2;   // t < 2^19
 #ifndef VRC_JUMP_RING
 #define VRC_JUMP_RING 4
 #endif
@@ -210,8 +208,35 @@ VRC_HD void pair_solve(bool active, int32_t ia, int32_t ib, int32_t &s_out, int3
     while (VRC_WAVE_ANY(euclid_busy(c))) euclid_step(c);
     euclid_finish(c, ib, s_out, g_out);
 }
-struct JumpEntry { int32_t s, g; };            // g == 0: no entry, g == 255: a gcd of 255 or more (solve on the spot)
-VRC_HD uint32_t jump_entry_pack(int32_t s, int32_t g) { return (uint32_t)s | ((uint32_t)(g < 255 ? g : 255) << 24); }
+struct JumpEntry { int32_t s, g; };            // g == 0: no entry
+// Two formats in one dword.  Small gcd (g <= 127, all but ~0.5 % of the pairs): s in bits 0-23, g in bits 24-30.  Large gcd: bit 31
+// set, bits 26-30 = (bits of g) - 8, then g, then s mod (ib / g) -- s is only ever multiplied with differences that g divides, so
+// it is needed modulo ib / g and the two together never take more than 26 bits.  (Until round 4 a gcd of 255 or more meant "solve
+// this pair afresh in every jump that meets it": 0.18 M such lanes made 8.6 M lanes of the headline frame wait for an
+// on-the-spot Euclid run.  The large format is written and decoded behind a wave vote: the hot path pays one compare.)
+VRC_HD uint32_t jump_entry_pack(int32_t s, int32_t g, int32_t ib) {
+    uint32_t d = (uint32_t)s | ((uint32_t)g << 24);
+    const bool big = g >= 128;
+    if (VRC_WAVE_ANY(big)) {
+        const int32_t gg = big ? g : 128;
+        int32_t rem, r2;
+        const int32_t ibr = floordiv(ib, gg, recip_d(gg), rem);           // exact: g divides ib
+        (void)floordiv(s, ibr > 0 ? ibr : 1, recip_d(ibr > 0 ? ibr : 1), r2);   // r2 = s mod (ib / g)
+        const uint32_t k = 32u - (uint32_t)__builtin_clz((uint32_t)gg);   // bits of g: 8 .. 24
+        if (big) d = 0x80000000u | ((k - 8u) << 26) | ((uint32_t)gg << (26u - k)) | (uint32_t)r2;
+    }
+    return d;
+}
+VRC_HD JumpEntry jump_entry_unpack(uint32_t d) {
+    JumpEntry en;
+    en.s = (int32_t)(d & 0xffffffu); en.g = (int32_t)(d >> 24);
+    const bool big = (int32_t)d < 0;
+    if (VRC_WAVE_ANY(big)) {
+        const uint32_t k = ((d >> 26) & 31u) + 8u, low = 26u - (k > 26u ? 26u : k);
+        if (big) { en.g = (int32_t)((d & 0x03ffffffu) >> low); en.s = (int32_t)(d & ((1u << low) - 1u)); }
+    }
+    return en;
+}
 
 // Builds one row (binade kJumpFirstBinade + row, the three pairs) of the table of every lane with `active` set; the
 // other lanes idle through the loop.  A pair one of whose axes cannot have a progression in that binade gets "no entry".
@@ -228,13 +253,18 @@ VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float
     while (VRC_WAVE_ANY(euclid_busy(cxy) || euclid_busy(cxz) || euclid_busy(cyz))) {
         euclid_step(cxy); euclid_step(cxz); euclid_step(cyz);
     }
-    if (active) {
+    if (active) solves += (vxy ? 1u : 0u) + (vxz ? 1u : 0u) + (vyz ? 1u : 0u);
+    {   // (outside the `active` branch: the large-gcd format is packed behind a vote of the whole wave)
         int32_t s, g;
         const int slot = row % R;
-        euclid_finish(cxy, iy, s, g); tab[(3 * slot + 0) * stride] = vxy ? jump_entry_pack(s, g) : 0u;
-        euclid_finish(cxz, iz, s, g); tab[(3 * slot + 1) * stride] = vxz ? jump_entry_pack(s, g) : 0u;
-        euclid_finish(cyz, iz, s, g); tab[(3 * slot + 2) * stride] = vyz ? jump_entry_pack(s, g) : 0u;
-        solves += (vxy ? 1u : 0u) + (vxz ? 1u : 0u) + (vyz ? 1u : 0u);
+        euclid_finish(cxy, iy, s, g); const uint32_t dxy = jump_entry_pack(vxy ? s : 0, vxy ? g : 1, iy);
+        euclid_finish(cxz, iz, s, g); const uint32_t dxz = jump_entry_pack(vxz ? s : 0, vxz ? g : 1, iz);
+        euclid_finish(cyz, iz, s, g); const uint32_t dyz = jump_entry_pack(vyz ? s : 0, vyz ? g : 1, iz);
+        if (active) {
+            tab[(3 * slot + 0) * stride] = vxy ? dxy : 0u;
+            tab[(3 * slot + 1) * stride] = vxz ? dxz : 0u;
+            tab[(3 * slot + 2) * stride] = vyz ? dyz : 0u;
+        }
     }
 }
 // rows stretch_jump() will read for these intersection_t: one per axis pair that shares a binade inside the table
@@ -282,11 +312,9 @@ VRC_HD JumpEntry jump_table_entry(const uint32_t *tab, int stride, uint32_t rows
     if (have) { en.s = 12345 + pair; en.g = 1; }
     return en;
 #endif
-    if (have) {
-        const uint32_t d = tab[(3 * (int)(row % (uint32_t)R) + pair) * stride];
-        en.s = (int32_t)(d & 0xffffffu); en.g = (int32_t)(d >> 24);
-    }
-    return en;
+    // (the decode sits outside the `have` branch: its large-gcd half is behind a vote of the whole wave)
+    const uint32_t d = have ? tab[(3 * (int)(row % (uint32_t)R) + pair) * stride] : 0u;
+    return jump_entry_unpack(d);
 }
 
 // One regular axis pair in a common binade: the consumed events are Ma + i*ia (0 <= i < ma) and Mb + j*ib (0 <= j < mb),
@@ -350,7 +378,7 @@ VRC_HD PairTies pair_count(const PairProbe &p, int32_t Ma, int32_t ia, int32_t m
     return out;
 }
 VRC_HD PairTies pair_ties(bool active, JumpEntry entry, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
-    const bool solve = active && (entry.g == 0 || entry.g == 255);   // no entry (below t = 128, beyond the table, evicted) or a gcd >= 255
+    const bool solve = active && entry.g == 0;                    // no entry: below t = 128, beyond the table, evicted
 #if defined(VRC_SCHED_STATS) && defined(__HIP_DEVICE_COMPILE__)
     if (solve) atomicAdd(&g_jump_private_solves[0], 1ULL);
     if (VRC_WAVE_ANY(solve) && active && !solve) atomicAdd(&g_jump_private_solves[1], 1ULL);

@@ -386,6 +386,11 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                 // (a block that found no table slot has no table: it never jumps.  Tested on the pointer, which is live anyway:
                 // one more value held through the loop costs this kernel 2 % in spills)
                 want = (kLdsTab || jtab != nullptr) && est >= jump_min_run;
+                // ... and only once every t has reached the table's first binade (t >= 128): below it a pair has no table row and
+                // is solved on the spot by every jump that meets it -- with the threshold at 64 that was 5.2 M on-the-spot Euclid
+                // runs per headline frame (11 M lanes waiting for them), 2.28 -> 2.21 ms without them.  A ray spends ~200
+                // iterations below t = 128, the binades there are short, and the step loop takes them
+                want = want && fminf(fminf(r.itx, r.ity), r.itz) >= (float)(1 << VRC_JUMP_FIRST_LOG2);
                 // (round 4: a second, lower threshold for lanes whose three t are all inside the table's binades -- "always jump once
                 // t >= 128" -- 1 / 8 / 24 iterations: 2.57 / 2.63 / 2.56 ms against 2.50: the pass, ~500 instructions on its straight
                 // path, is what a short run cannot pay for, not the Euclid runs)
