@@ -309,6 +309,12 @@ def main():
     if world != n and world != 1:
         raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
 
+    # torch is imported FIRST (the import alone does not touch the GPU): it brings its own bundled HIP runtime, and a process
+    # that loads libvrc.so before it ends up with TWO HIP runtimes -- the system's, which libvrc.so would bind to, and torch's --
+    # in which every kernel of this benchmark runs 6-7 % slower (measured round 4: 2.35 vs 2.19 ms on the headline frame,
+    # tools/bench_bisect.py).  With torch loaded first libvrc.so binds to the runtime that is already there.
+    import torch
+    import torch.distributed as dist
     # build BEFORE anything touches the GPU (a GPU-initialised process must not spawn compilers); under torchrun the
     # local rank 0 builds, the others meet it at the first barrier below before they import the library
     import __graft_entry__ as graft
@@ -318,8 +324,6 @@ def main():
     elif local_rank == 0:
         graft.build()
 
-    import torch
-    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
     # test hook (tests/ and rehearsals on a 1-GPU box only): let several ranks share GPU 0 over gloo so that the

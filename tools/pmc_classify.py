@@ -6,10 +6,17 @@ ubench kernel, the share of its VALU instructions that each class counter saw.
 import collections, csv, glob, os, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "*", "*_counter_collection.csv"))):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))       # this pass: kernel -> counter -> sum
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
         if k.startswith("k_"):
-            acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            per[k][row["Counter_Name"]] += float(row["Counter_Value"])
+    for k, cs in per.items():                      # every pass carries SQ_INSTS_VALU: a class counter's share of ITS pass
+        tot = cs.get("SQ_INSTS_VALU", 0.0)
+        for c, v in cs.items():
+            if c != "SQ_INSTS_VALU" and tot:
+                acc[k][c] = v / tot
+        acc[k]["SQ_INSTS_VALU"] = 1.0
 for k in sorted(acc):
     tot = acc[k].get("SQ_INSTS_VALU", 0.0)
     if not tot:
