@@ -136,6 +136,12 @@ int vrc_assign_lights(vrc_caster *h, const float *packed, const int32_t *light_c
  *   octree_bias (1: the :353-354 term as in the reference; 0: without it)
  *   hit_records (1: the 8 x int32 record per pixel behind vrc_read_hits; 0: none -- the reference has none)
  *   stepping_mode (0: exact per-voxel DDA, bit-identical to the array branch; 1: node-exit jumps, DESIGN.md "mode B")
+ *   coarse_log2 (-1: by depth = min(depth - 2, 9) from depth 5; 0: none; k: 2^k cells per axis, at most min(depth - 2, 10)):
+ *     the levels of the tree above level k as a dense table in HBM, built on the device from the descriptor array at the first
+ *     vrc_compute after a tree is assigned (8 << 3k bytes: 1 GB at k = 9).  Both SVO kernels read it instead of descending
+ *     from the root; frames, hit records and the exact mode's counters are the same with and without it
+ *   jump_tables_lds (2: the Euclid tables of the exact closed-form jumps live in LDS when they fit at full occupancy;
+ *     1 / 0: always / never)   jump_min_run (closed-form jumps for runs of at least this many iterations; 1 << 24: off)
  * Settings stay live after vrc_validate (overwrite_setting needs no recompile); structural ones are re-checked by
  * every vrc_compute, which fails with an error code instead of launching on a bad value.                            */
 int vrc_setting_add(vrc_caster *h, const char *name, const char *define, int64_t value);
@@ -195,6 +201,7 @@ typedef struct vrc_memory {
     uint64_t viewport_bytes, image_bytes, hit_bytes, octree_bytes;
     int32_t  octree_shared;           /* 1: the arrays belong to rank 0 (same GPU) */
     int32_t  peer_access;             /* -1: rank 0 or on rank 0's GPU; 1: direct peer access to rank 0's GPU; 0: staged by the runtime */
+    uint64_t coarse_bytes;            /* the dense table of the tree's top (setting coarse_log2), 0 before the first frame */
 } vrc_memory;
 int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out);
 

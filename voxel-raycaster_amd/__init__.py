@@ -54,7 +54,8 @@ class BuildInfo(C.Structure):
 
 class Memory(C.Structure):
     _fields_ = [("device", C.c_int32), ("rows", C.c_int32), ("viewport_bytes", C.c_uint64), ("image_bytes", C.c_uint64),
-                ("hit_bytes", C.c_uint64), ("octree_bytes", C.c_uint64), ("octree_shared", C.c_int32), ("peer_access", C.c_int32)]
+                ("hit_bytes", C.c_uint64), ("octree_bytes", C.c_uint64), ("octree_shared", C.c_int32), ("peer_access", C.c_int32),
+                ("coarse_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -1010,6 +1010,8 @@ int compute_async_one(vrc_caster *h) {
                 h->coarse_log2 = (int)lc; h->coarse_root = p.root_index; h->coarse_depth = p.log2_dim;
             }
             p.coarse = h->d_coarse; p.coarse_log2 = (int32_t)lc;
+        } else {
+            release(h->d_coarse); h->coarse_log2 = 0;             // the setting went to "none": the table goes too
         }
     }
     // exact closed-form jumps: on from depth 12; the threshold depends on where the Euclid tables live (LDS when stack + tables
@@ -1170,6 +1172,7 @@ int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out) {
     out->octree_bytes = q->d_desc ? q->n_desc * 8 + (q->d_attach_lookup ? q->n_desc * 4 + std::max<uint64_t>(q->n_attach, 1) * 8 : 0) : 0;
     out->octree_shared = q->owns_desc ? 0 : 1;
     out->peer_access = q->peer_access;
+    out->coarse_bytes = q->d_coarse ? (uint64_t)sizeof(uint64_t) << (3 * q->coarse_log2) : 0;
     return VRC_OK;
 }
 
