@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     const bool use_single = kTuned ? true : p.single_step != 0;
     const int shade_threshold = kTuned ? kDefaultShadeThreshold : p.shade_threshold;
     const float jump_min_run = kTuned ? (float)(kLdsTab ? kDefaultJumpMinRunLds : kDefaultJumpMinRun) : (float)p.jump_min_run;   // estimated iterations that make a jump worth its block
-    const int safe_cap = kTuned ? kDefaultSafeSteps : p.safe_steps;   // iterations per safe run (phase 2a)
+    const int safe_cap = kTuned ? (kJump ? kDefaultSafeStepsJump : kDefaultSafeSteps) : p.safe_steps;   // iterations per safe run (phase 2a)
     const int burst_cap = kTuned ? kDefaultBurstSteps : p.burst_steps;   // ordinary steps per round and lane (compare/select loop)
     const int exact_cap = (use_arith && use_safe) ? (kTuned ? kDefaultExactSteps : p.exact_steps) : burst_cap;
     const float safe_limit = safe_t_limit(safe_cap);
@@ -926,7 +926,7 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
         const size_t lds = svo_stack_bytes(p) + (lds_tab ? kLdsTabBytes : 0);
         const bool tuned = (!jump || p.jump_min_run == (lds_tab ? kDefaultJumpMinRunLds : kDefaultJumpMinRun)) &&
                            p.widen_nodes != 0 && p.arith_mask != 0 && p.safe_run != 0 && p.single_step != 0 &&
-                           p.shade_threshold == kDefaultShadeThreshold && p.safe_steps == kDefaultSafeSteps &&
+                           p.shade_threshold == kDefaultShadeThreshold && p.safe_steps == (jump ? kDefaultSafeStepsJump : kDefaultSafeSteps) &&
                            p.exact_steps == kDefaultExactSteps && p.burst_steps == kDefaultBurstSteps;
         if (jump && !lds_tab && (!p.jump_cache || !p.jump_slots || p.jump_slot_count < 1)) return hipErrorInvalidValue;
 #define VRC_LAUNCH(...) hipLaunchKernelGGL((raycast_svo_kernel<__VA_ARGS__>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p)

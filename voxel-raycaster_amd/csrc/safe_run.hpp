@@ -34,7 +34,10 @@
 namespace vrc {
 
 constexpr int kSafeMaxSteps = 256;     // most iterations per safe run the settings allow
-constexpr int kSafeUnroll = 16;         // iterations per loop trip of a safe run (setting safe_steps is rounded down to it)
+#ifndef VRC_SAFE_UNROLL
+#define VRC_SAFE_UNROLL 16
+#endif
+constexpr int kSafeUnroll = VRC_SAFE_UNROLL;   // iterations per loop trip of a safe run (setting safe_steps is rounded down to it)
 
 // largest threshold T a safe run of at most `steps` iterations may use (see the recovery bound above)
 VRC_SR float safe_t_limit(int steps) {

@@ -969,7 +969,6 @@ int compute_async_one(vrc_caster *h) {
     p.watchdog_flag = h->wd_flag;
     p.safe_run = (int32_t)setting_or(h, "safe_run", 1);
     p.single_step = (int32_t)setting_or(h, "single_step", 1);
-    p.safe_steps = (int32_t)std::min<int64_t>(256, std::max<int64_t>(2, setting_or(h, "safe_steps", vrc::kDefaultSafeSteps)));
     p.exact_steps = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(1, setting_or(h, "exact_steps", vrc::kDefaultExactSteps)));
     p.xcd_mode = (int32_t)setting_or(h, "xcd_mode", 1);
     p.lds_pad_bytes = (int32_t)std::min<int64_t>(120 * 1024, std::max<int64_t>(0, setting_or(h, "lds_pad_bytes", 0)));
@@ -1021,6 +1020,8 @@ int compute_async_one(vrc_caster *h) {
     p.jump_min_run = (int32_t)std::min<int64_t>(vrc::kJumpOff, std::max<int64_t>(1, setting_or(h, "jump_min_run",
                                     p.log2_dim >= vrc::kDefaultJumpMinDepth ? (tables_in_lds ? vrc::kDefaultJumpMinRunLds : vrc::kDefaultJumpMinRun)
                                                                             : vrc::kJumpOff)));
+    p.safe_steps = (int32_t)std::min<int64_t>(256, std::max<int64_t>(2, setting_or(h, "safe_steps",
+                                    p.jump_min_run < vrc::kJumpOff ? vrc::kDefaultSafeStepsJump : vrc::kDefaultSafeSteps)));
     if (svo && p.stepping_mode == 0 && p.jump_min_run < vrc::kJumpOff && !tables_in_lds) {
         const int rc = ensure_jump_cache(h, nblocks);
         if (rc != VRC_OK) return rc;

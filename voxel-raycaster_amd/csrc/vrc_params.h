@@ -20,17 +20,28 @@ static_assert((kTileW & (kTileW - 1)) == 0 && kTileW >= 1 && kTileW <= 64, "tile
 constexpr int kTilesPerBlock = VRC_TILES_PER_BLOCK;   // 256-thread block = 4 horizontally adjacent tiles (32x8 px)
 constexpr int kBlockThreads = 64 * kTilesPerBlock;
 // defaults of the scheduling knobs (settings of the same names; the tuned kernel instances have them compiled in)
-constexpr int kDefaultBurstSteps = 48, kDefaultShadeThreshold = 64, kDefaultSafeSteps = 64, kDefaultExactSteps = 16;
+// iterations per safe run (setting safe_steps): short rounds since round 4 -- with the tree's top in the coarse table a node
+// event is cheap, and what a long safe run costs is the lanes that idle through it (38 % lane utilisation at 64).  Headline
+// frame, safe_steps x jump threshold: 64 x 64 2.21 ms, 32 x 32 2.13, 16 x 16 2.11, 8 x 8 2.25; without jumps (depth 11) 16 / 32 / 64:
+// 1.62 / 1.53 / 1.55 ms
+#ifndef VRC_DEFAULT_SAFE_STEPS
+#define VRC_DEFAULT_SAFE_STEPS 32
+#endif
+#ifndef VRC_DEFAULT_SAFE_STEPS_JUMP
+#define VRC_DEFAULT_SAFE_STEPS_JUMP 16
+#endif
+constexpr int kDefaultBurstSteps = 48, kDefaultShadeThreshold = 64, kDefaultSafeSteps = VRC_DEFAULT_SAFE_STEPS, kDefaultExactSteps = 16;
+constexpr int kDefaultSafeStepsJump = VRC_DEFAULT_SAFE_STEPS_JUMP;      // ... of the instances with the closed-form jumps
 // exact closed-form jumps (exact_jump.hpp): estimated iterations from which a lane asks for the jump block, and the tree
 // depth from which they are on by default (measured: depth 10 loses 15 %, depth 12 gains 15 %, depth 16 is 3.3x faster)
 #ifndef VRC_DEFAULT_JUMP_MIN_RUN
 #define VRC_DEFAULT_JUMP_MIN_RUN 96
 #endif
 constexpr int kDefaultJumpMinRun = VRC_DEFAULT_JUMP_MIN_RUN, kDefaultJumpMinDepth = 12;
-// ... and with the tables in LDS (depth 12: stack + tables fit at 5 blocks per CU) a jump is cheaper: 48 / 64 / 96 / 128 measured
-// 2.56 / 2.50 / 2.52 / 2.53 ms on the headline frame (round 4)
+// ... and with the tables in LDS a jump is cheaper: 48 / 64 / 96 / 128 measured 2.56 / 2.50 / 2.52 / 2.53 ms on the headline frame
+// before the coarse table, 16 the best with it and 16-iteration safe runs (see kDefaultSafeStepsJump below)
 #ifndef VRC_DEFAULT_JUMP_MIN_RUN_LDS
-#define VRC_DEFAULT_JUMP_MIN_RUN_LDS 64
+#define VRC_DEFAULT_JUMP_MIN_RUN_LDS 16
 #endif
 constexpr int kDefaultJumpMinRunLds = VRC_DEFAULT_JUMP_MIN_RUN_LDS;
 constexpr int kJumpOff = 1 << 24;      // jump_min_run >= this: the instances without the jump block
