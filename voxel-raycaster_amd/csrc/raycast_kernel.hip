@@ -267,7 +267,10 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         const uint64_t a = p.attachments[p.attach_lookup[node]];
         return (int)(int8_t)(a >> (8 * ((x & 1) | ((y & 1) << 1) | ((z & 1) << 2))));
     };
-    const bool widen = kTuned ? true : p.widen_nodes != 0;
+#ifndef VRC_TUNED_WIDEN
+#define VRC_TUNED_WIDEN true
+#endif
+    const bool widen = kTuned ? VRC_TUNED_WIDEN : p.widen_nodes != 0;
     // park the ray in the empty node of size 2^b around its voxel.  The parent's valid mask is at hand, so the
     // box is widened over empty siblings that lie ahead of the ray: fewer node events, same lookups (a sibling
     // the mask calls empty would have been found empty without any descriptor read).

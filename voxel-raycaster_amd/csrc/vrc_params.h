@@ -30,7 +30,10 @@ constexpr int kBlockThreads = 64 * kTilesPerBlock;
 #ifndef VRC_DEFAULT_SAFE_STEPS_JUMP
 #define VRC_DEFAULT_SAFE_STEPS_JUMP 16
 #endif
-constexpr int kDefaultBurstSteps = 48, kDefaultShadeThreshold = 64, kDefaultSafeSteps = VRC_DEFAULT_SAFE_STEPS, kDefaultExactSteps = 16;
+#ifndef VRC_DEFAULT_EXACT_STEPS
+#define VRC_DEFAULT_EXACT_STEPS 16
+#endif
+constexpr int kDefaultBurstSteps = 48, kDefaultShadeThreshold = 64, kDefaultSafeSteps = VRC_DEFAULT_SAFE_STEPS, kDefaultExactSteps = VRC_DEFAULT_EXACT_STEPS;
 constexpr int kDefaultSafeStepsJump = VRC_DEFAULT_SAFE_STEPS_JUMP;      // ... of the instances with the closed-form jumps
 // exact closed-form jumps (exact_jump.hpp): estimated iterations from which a lane asks for the jump block, and the tree
 // depth from which they are on by default (measured: depth 10 loses 15 %, depth 12 gains 15 %, depth 16 is 3.3x faster)
