@@ -295,6 +295,8 @@ def main():
                     help="N > 1: weak = the frame grows to H*N rows over the same field of view; strong = the W x H frame is row-tiled over the N ranks")
     ap.add_argument("--thickness", type=int, default=2, help="shell thickness of the terrain (device-built scenes, depth >= 14; configs[4]: 33)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-survey-camera", action="store_true",
+                    help="skip the survey_camera leg (the rocprofv3 --stats run: every launch of the kernel is then the headline frame)")
     ap.add_argument("--no-build", action="store_true",
                     help="never spawn a compiler: fail if a library is stale (required under rocprofv3: the profiler's preloaded "
                          "library must not be inherited by child processes of a GPU-initialised program)")
@@ -485,7 +487,7 @@ def main():
                          "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"], "valu_issue": issue,
                          "pmc_source": pmc_note, "kernel_source_hash": kernel_source_hash()},
         }
-        if world == 1 and not sc.get("device_built"):
+        if world == 1 and not sc.get("device_built") and not args.no_survey_camera:
             out["survey_camera"] = survey_camera_leg(sc, c, args)
         if world == 1 and not args.no_cpu_baseline and not sc.get("device_built"):
             out.update(supplementary(sc, c, W, H, local_rank, args, rays_per_step))

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 python __graft_entry__.py > $OUT/build.log 2>&1
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-build > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-survey-camera --no-build > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b -o stats -- python3 $GRAFT_REPO_ROOT/tools/frames.py --mode 1 --frames 20 --hit-records 0 > $OUT/stats_b.log 2>&1
 run() { dir=$1; name=$2; shift; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$dir/$name -o $name -- python3 $GRAFT_REPO_ROOT/tools/frames.py --mode $MODE --frames 3 --hit-records 0 > $OUT/$dir/$name.log 2>&1; }
 for MODE in 0 1; do

@@ -23,7 +23,7 @@ def pmc(path):
 
 open(P(f"{rnd}_kernel_stats.txt"), "w").write(
     f"# MI355X, {label}\n"
-    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-build   (exact mode, the headline kernel)\n"
+    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-survey-camera --no-build   (exact mode: every launch is the headline frame)\n"
     + open(g("stats", "stats_kernel_stats.csv")).read()
     + "\n# rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/frames.py --mode 1 --frames 20   (stepping mode 1, node-exit jumps)\n"
     + open(g("stats_b", "stats_kernel_stats.csv")).read()
