@@ -94,6 +94,21 @@ if os.path.exists(g("valu_classes.txt")):
     open(P(f"{rnd}_valu_classes.txt"), "w").write(
         "# which SQ_INSTS_VALU_<class> counter counts which opcode on gfx950: rocprofv3 --pmc over tools/ubench/valu_issue (one opcode per kernel),\n"
         "# share of the kernel's SQ_INSTS_VALU each class counter saw (tools/pmc_classify.py)\n" + open(g("valu_classes.txt")).read())
+# the instances that are not the headline (tools/gpu_profile.sh pmc2)
+others = [("c4_4k_2lights", "C4 geometry: depth 12, 3840x2160, 2 lights (multi-light instance)"),
+          ("headline_4lights", "headline scene with 4 lights"),
+          ("c2_d10_primary", "C2: depth 10, 1920x1080, primary rays only (no jumps below depth 12)"),
+          ("headline_no_jumps", "headline frame with jump_min_run off (the plain step-loop instance)")]
+blocks = []
+for name, title in others:
+    if os.path.exists(g(f"pmc_{name}_summary.txt")):
+        blocks.append(f"## {title}\n" + open(g(f"pmc_{name}_summary.txt")).read())
+if blocks:
+    open(P(f"{rnd}_pmc_other_instances.txt"), "w").write(
+        "# per-dispatch PMC averages of the SVO kernel's other instances (tools/gpu_profile.sh pmc2: separate --pmc passes, kernel-trace only;\n"
+        f"# FETCH_SIZE / WRITE_SIZE in KiB, see {rnd}_pmc_exact.txt for the gfx950 correction); the last line of each block is the frames.py line of the FETCH_SIZE pass\n\n"
+        + "\n".join(blocks))
+open(P(f"{rnd}_bench_line.json"), "w").write(line + "\n")
 hbm = int((2 * v0["FETCH_SIZE"] + v0["WRITE_SIZE"]) * 1024)
 json.dump({"kernel_source_hash": bench.kernel_source_hash(), "hbm_bytes_per_launch": hbm, "fetch_size_kib_raw": v0["FETCH_SIZE"],
            "write_size_kib_raw": v0["WRITE_SIZE"],
