@@ -429,3 +429,33 @@ def test_oracle_matches_the_reference_kernel_vectors(path, atlas):
     buf, root = orc.octree_generate(s["grid"], s["dim"])
     oimg, ohits, octr = refcompare.oracle_frame(s, w, h, atlas, buf, root, z["trig"], threads=4)
     refcompare.compare(s, w, h, z["records"], oimg, ohits, octr, verbose=False)
+
+
+def test_oracle_mode_b_coarse_table_restated_reads():
+    """The coarse top table of round 4 as the oracle restates it for mode B (svo_locate_from): one read stands for the descent
+    from the root to the table's level.  Everything but the read count is the plain traversal's -- image, hit voxel, face,
+    material, flags, step count -- for every table level; a table at level L never reads more than L - 1 descriptors fewer
+    per cell crossing than it saves, and level 0 is the canonical count."""
+    s = scenes.floor_pillars(32)
+    dim, w, h = s["dim"], 64, 48
+    buf, root = orc.octree_generate(s["grid"], dim)
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = s["lights"]
+    atlas = scenes.hash_atlas()
+
+    def run(coarse, mode=1):
+        return orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=li, atlas=atlas, tile_dim=(16, 16),
+                           descriptors=buf, root_index=root, octree_dim=dim, using_octree=0, max_distance=3 * dim,
+                           stepping_mode=mode, coarse_log2=coarse)
+
+    img0, hits0, ctr0 = run(0)
+    reads = {0: ctr0["n_desc"]}
+    for coarse in (-1, 1, 2, 3):
+        img, hits, ctr = run(coarse)
+        assert np.array_equal(img.view(np.uint32), img0.view(np.uint32)) and np.array_equal(hits[..., :7], hits0[..., :7])
+        assert {k: v for k, v in ctr.items() if k != "n_desc"} == {k: v for k, v in ctr0.items() if k != "n_desc"}
+        reads[coarse] = ctr["n_desc"]
+    assert reads[-1] == reads[3]                       # depth 5: the rule gives level min(5 - 2, 9) = 3
+    assert len(set(reads.values())) > 1                # the table does change the count
+    # the exact mode never takes the table path in the oracle: its count is the canonical one whatever the field says
+    assert run(3, mode=0)[2] == run(0, mode=0)[2]
