@@ -339,7 +339,10 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
 
     const bool use_arith = kTuned ? true : p.arith_mask != 0;
     const bool use_safe = kTuned ? true : p.safe_run != 0;
-    const bool use_single = kTuned ? true : p.single_step != 0;
+#ifndef VRC_TUNED_SINGLE
+#define VRC_TUNED_SINGLE true
+#endif
+    const bool use_single = kTuned ? VRC_TUNED_SINGLE : p.single_step != 0;
     const int shade_threshold = kTuned ? kDefaultShadeThreshold : p.shade_threshold;
     const float jump_min_run = kTuned ? (float)(kLdsTab ? kDefaultJumpMinRunLds : kDefaultJumpMinRun) : (float)p.jump_min_run;   // estimated iterations that make a jump worth its block
     const int safe_cap = kTuned ? (kJump ? kDefaultSafeStepsJump : kDefaultSafeSteps) : p.safe_steps;   // iterations per safe run (phase 2a)
