@@ -23,9 +23,11 @@ for src in ("raycast_kernel.hip", "raycast_jump_kernel.hip", "svo_builder_gpu.hi
         elif cur is not None:
             cur[k.split(" [")[0]] = v
 print("# kernel resource usage, gfx950 (hipcc " + " ".join(f for f in g.HIP_FLAGS if f.startswith("-O") or f.startswith("-f")) + ")")
-print("# raycast_svo_kernel<kJump, kMulti, kTuned>: kJump = exact closed-form jumps compiled in (96 VGPRs: 5 blocks per CU; the others 80: 6),")
-print("# kMulti = multi-light extension, kTuned = scheduling knobs at their defaults (compile-time constants).  Static LDS only: the")
-print("# traversal stack is dynamic LDS, (log2 dim - 1) * 2 KB per block (one level less in mode B).")
+print("# raycast_svo_kernel<kJump, kMulti, kTuned, kLdsTab, kCoarse>: kJump = exact closed-form jumps compiled in (96 VGPRs: 5 blocks per CU; the")
+print("# others 80: 6), kMulti = multi-light extension, kTuned = scheduling knobs at their defaults (compile-time constants), kLdsTab = the jumps'")
+print("# Euclid tables in LDS (12 KB of dynamic LDS per block), kCoarse = the tree's top from the dense table (the traversal stack then holds the")
+print("# levels below it only: (log2 dim - coarse_log2) * 2 KB of dynamic LDS per block instead of (log2 dim - 1) * 2 KB).  Static LDS only.")
+print("# raycast_jump_kernel<kMulti, kCoarse> = mode B.  The headline instance is raycast_svo_kernel<true, false, true, true, true>.")
 print("| kernel | file | VGPRs | SGPRs | scratch B/lane | waves/SIMD | static LDS B |")
 print("|---|---|---|---|---|---|---|")
 for r in rows:
