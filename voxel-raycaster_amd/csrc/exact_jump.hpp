@@ -169,18 +169,30 @@ constexpr int kJumpTableDwords = 3 * kJumpRing;   // one dword per pair and row 
 
 // s and g with s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib; 1 <= ia, ib < 2^24.  Extended Euclid on exact integers
 // held in floats, two steps per trip with the roles of the two remainders alternating (no conditional swaps):
-//     (r0, s0) -= q  * (r1, s1)     q  = floor(r0 / r1)        then        (r1, s1) -= q' * (r0, s0)     q' = floor(r1 / r0)
-// with the invariant r_i == s_i * ia (mod ib).  The quotient estimate is rounded DOWN (never above the true floor) and
-// then raised by one where the remainder allows, so remainders stay non-negative and every fma is exact; for quotients
-// below 2^20 that is the exact floor, a larger one may come out short -- the step is then only partial, the other
-// remainder's step finds a zero quotient and does nothing, and the next trip finishes it.  A zero remainder makes every
-// later step a no-op, so lanes simply idle until the last chain of the wave is through.
+//     (r0, s0) -= q  * (r1, s1)     q  = nearest(r0 / r1)      then        (r1, s1) -= q' * (r0, s0)     q' = nearest(r1 / r0)
+// with the invariant r_i == s_i * ia (mod ib), remainders folded to >= 0 (see euclid_reduce).  A zero remainder makes every
+// later step a no-op, so lanes simply idle until the last chain of the wave is through.  (The floor form of rounds 2-3: the
+// quotient estimate rounded DOWN and raised by one where the remainder allows; a quotient above 2^20 may come out short, the
+// step is then partial and the next trip finishes it.)
 struct EuclidChain { float r0, s0, r1, s1; };
 VRC_HD void euclid_init(EuclidChain &c, bool active, int32_t ia, int32_t ib) {
     c.r0 = (float)ib; c.s0 = 0.0f; c.r1 = active ? (float)ia : 0.0f; c.s1 = 1.0f;
 }
 // (a, sa) -= floor(a / b) * (b, sb); nothing when b == 0
 VRC_HD void euclid_reduce(float &a, float &sa, float b, float sb) {
+#ifndef VRC_EUCLID_FLOOR
+    // LEAST-ABSOLUTE-REMAINDER step (round 4): q = the integer nearest to a / b, the remainder n = a - q b lies in about
+    // [-b/2, b/2] and is folded back to >= 0 together with its cofactor: -n == (-t) * ia (mod ib).  About 30 % fewer steps than
+    // the floor form below (rounds 2-3; -DVRC_EUCLID_FLOOR), one instruction less per step, and the headline frame 2.10 -> 1.99 ms.
+    // Any integer q keeps the invariant r == s * ia (mod ib); the estimate is within q 2^-22 + 1/2 of a / b, so |n| <= b (1/2 +
+    // q 2^-22) < b keeps the chain shrinking and far below 2^24: both fused multiply-adds are exact.
+    float q = __builtin_rintf(a * fast_rcp(b));                   // (b == 0: inf or NaN)
+    q = (b == 0.0f) ? 0.0f : q;
+    const float n = __builtin_fmaf(-q, b, a);                     // exact
+    const float t = __builtin_fmaf(-q, sb, sa);                   // exact
+    a = __builtin_fabsf(n);
+    sa = n < 0.0f ? -t : t;
+#else
     float q = __builtin_floorf(a * (fast_rcp(b) * 0.99999952f));  // <= floor(a / b), short by < 2^-20 relative (b == 0: inf or NaN)
     q = (b == 0.0f) ? 0.0f : q;
     float n = __builtin_fmaf(-q, b, a);                           // exact, >= 0
@@ -189,6 +201,7 @@ VRC_HD void euclid_reduce(float &a, float &sa, float b, float sb) {
     n -= up ? b : 0.0f;
     sa = __builtin_fmaf(-q, sb, sa);                              // exact: the cofactors stay below ib in magnitude
     a = n;
+#endif
 }
 VRC_HD void euclid_step(EuclidChain &c) {
     euclid_reduce(c.r0, c.s0, c.r1, c.s1);
