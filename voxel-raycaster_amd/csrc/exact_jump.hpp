@@ -191,7 +191,7 @@ VRC_HD void euclid_reduce(float &a, float &sa, float b, float sb) {
     const float n = __builtin_fmaf(-q, b, a);                     // exact
     const float t = __builtin_fmaf(-q, sb, sa);                   // exact
     a = __builtin_fabsf(n);
-    sa = n < 0.0f ? -t : t;
+    sa = u2f(f2u(t) ^ (f2u(n) & 0x80000000u));                    // -t where n < 0 (two full-rate bit operations instead of compare + select)
 #else
     float q = __builtin_floorf(a * (fast_rcp(b) * 0.99999952f));  // <= floor(a / b), short by < 2^-20 relative (b == 0: inf or NaN)
     q = (b == 0.0f) ? 0.0f : q;
