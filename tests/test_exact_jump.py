@@ -19,8 +19,8 @@ SRC = os.path.join(ROOT, "tools", "jumptest", "jump_vs_loop.cpp")
 
 
 @pytest.mark.parametrize("flags,seed", [([], 101), (["-DVRC_JUMP_FUZZ_RCP"], 202), (["-DVRC_JUMP_RING=3"], 303),
-                                        (["-DVRC_EUCLID_FLOOR", "-DVRC_JUMP_FUZZ_RCP"], 404)],
-                         ids=["exact-rcp", "fuzzed-rcp", "ring-of-3-rows", "floor-euclid"])
+                                        (["-DVRC_EUCLID_FLOOR", "-DVRC_JUMP_ROOM", "-DVRC_JUMP_FUZZ_RCP"], 404)],
+                         ids=["exact-rcp", "fuzzed-rcp", "ring-of-3-rows", "round-3-forms"])
 def test_jump_equals_plain_loop(tmp_path, flags, seed):
     exe = str(tmp_path / "jump_vs_loop")
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", *flags, "-o", exe, SRC])

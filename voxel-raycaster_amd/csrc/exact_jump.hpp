@@ -432,11 +432,30 @@ VRC_HD JumpAxis jump_axis(float t, float d, int32_t n) {
     const int32_t ec = reg ? a.e : 64;
     a.inc = jump_axis_inc(ec, reg ? d : 1.0f, halfway);
     reg = reg && !(halfway && (a.tb & 1));                        // half-way case: needs an even mantissa (one real step settles it)
+#ifndef VRC_JUMP_ROOM
+    // (round 4; -DVRC_JUMP_ROOM: the form of round 3, with a division per axis for the steps the binade has room for)
+    // Does the value at the node face (n - 1 steps on) still lie in this binade?  An exact 48-bit test instead of a division: if it
+    // does, that value is the axis' bound E; if not, E is the LARGEST FLOAT OF THE BINADE -- not an event of the axis, only a bound:
+    // every event of the axis up to it is consumed (jump_count gets their number by its one division) and the axis' next event
+    // lies in the next binade, beyond every value the stretch consumes.
+    const uint32_t mant = (uint32_t)a.tb & 0x7fffffu, steps = (uint32_t)(n - 1), uinc = reg ? (uint32_t)a.inc : 64u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lo = __umul24(steps, uinc), hi = __umulhi(steps, uinc);
+#else
+    const uint64_t p64 = (uint64_t)steps * uinc;
+    const uint32_t lo = (uint32_t)p64, hi = (uint32_t)(p64 >> 32);
+#endif
+    const bool fits = hi == 0u && lo <= 0x7fffffu - mant;
+    a.reg = reg;
+    a.c = (reg && fits) ? n - 1 : (reg ? -1 : 0);                 // -1: E is the binade's end, the event count comes from jump_count's division
+    a.E = reg ? (fits ? u2f((uint32_t)a.tb + lo) : u2f(((uint32_t)a.tb & 0xff800000u) | 0x7fffffu)) : t;
+#else
     // steps that stay inside the binade: floor((2^24 - 1 - M) / inc), exact (a short estimate would cost a whole extra jump)
     const int32_t room = floordiv_small(0x7fffff - (a.tb & 0x7fffff), reg ? a.inc : 64);
     a.reg = reg;
     a.c = reg ? (n - 1 < room ? n - 1 : room) : 0;
     a.E = reg ? u2f((uint32_t)(a.tb + mul24(a.c, a.inc))) : t;
+#endif
     a.m = 0; a.last = t; a.hitX = false;
     return a;
 }
@@ -444,9 +463,15 @@ VRC_HD JumpAxis jump_axis(float t, float d, int32_t n) {
 // events of the axis with value <= X, where X <= a.E
 VRC_HD void jump_count(JumpAxis &a, float t, float X) {
     const int32_t diff = (int32_t)f2u(X) - a.tb;                  // meaningful for t <= X < E: 0 <= diff < c*inc < 2^24
+#ifndef VRC_JUMP_ROOM
+    const bool mid = a.reg && X >= t && (X < a.E || a.c < 0);     // (X == E with E the binade's end: counted, not known)
+    const int32_t k = floordiv_small(mid ? diff : 0, mid ? a.inc : 64);
+    int32_t m = mid ? k + 1 : a.c + 1;
+#else
     const bool mid = a.reg && X >= t && X < a.E;
     const int32_t k = floordiv_small(mid ? diff : 0, mid ? a.inc : 64);
     int32_t m = (X == a.E) ? a.c + 1 : k + 1;
+#endif
     m = (X >= t) ? m : 0;
     a.m = m;
     a.last = (a.reg && m > 0) ? u2f((uint32_t)(a.tb + mul24(m - 1, a.inc))) : t;
