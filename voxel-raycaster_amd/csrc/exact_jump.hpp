@@ -16,14 +16,14 @@
 //   * the number of EQUAL values of two axes (a linear congruence: one extended-Euclid run per axis pair, binade and
 //     ray direction, kept in a per-ray table)
 // are closed forms.  stretch_jump() consumes every iteration up to and including the one that leaves the node -- or up
-// to the last value an axis has below its binade end, whichever comes first -- and reports how many loop iterations that
-// was.  It ALWAYS makes progress (>= 1 iteration): an axis outside the simple regime (t <= 0 or tiny, t not above
+// to the end of the binade of an axis whose node face lies beyond it, whichever comes first -- and reports how many loop
+// iterations that was.  It ALWAYS makes progress (>= 1 iteration): an axis outside the simple regime (t <= 0 or tiny, t not above
 // delta_t's binade, unsettled half-way case, increment below 64 ulps) is FROZEN, i.e. a one-element progression whose
 // single step is taken with one real float add and which bounds the stretch.  A stretch that ends early is simply
 // continued by the next call (or by the ordinary step loop, which is always correct).
 //
-// The Euclid runs are the expensive part (a loop of 15-25 dependent divisions) and a ray needs one per axis pair and
-// binade.  The increments depend on (delta_t, binade) only, so the runs are shared by the wave: when the first lane needs
+// The Euclid runs are the expensive part (a loop of ~10-16 dependent divisions, least-absolute-remainder steps) and a ray
+// needs one per axis pair and binade.  The increments depend on (delta_t, binade) only, so the runs are shared by the wave: when the first lane needs
 // binade e, the three pairs of EVERY lane whose ray keeps its direction are solved for e in one loop (jump_rows_build) and
 // kept in a per-ray table -- the rays of a tile reach a binade within a few rounds of each other.
 //
@@ -158,9 +158,9 @@ constexpr int kJumpBinades = 19 - VRC_JUMP_FIRST_LOG2;   // t < 2^19
 #define VRC_JUMP_RING 4
 #endif
 // rows kept per ray: a ring indexed by row % R (intersection_t only grows).  The functions below take R as a template
-// argument: 4 rows for tables in global memory, 3 rows -- 3 x 3 dwords x 256 threads = 9 KB per block -- for tables in LDS,
-// which is what fits beside the traversal stack of a depth-12 tree at 5 blocks per CU (round 4).  On the headline frame 3 and
-// 4 rows run the same; deep trees (rays that cross more binades) lose 3-4 % with 3.
+// argument: the kernel uses 4 rows everywhere (in LDS, [row][pair][thread]: 12 KB per block, or in the global table buffer);
+// 3 rows -- 9 KB -- were what fitted beside the 11-level traversal stack of a depth-12 tree before the coarse top table shrank
+// the stack (same speed on the headline frame, 3-4 % slower on deep trees whose rays cross more binades).
 constexpr int kJumpRing = VRC_JUMP_RING;      // the default R (host harness: -DVRC_JUMP_RING=3 / 4)
 template <int R> struct JumpRingMask;
 template <> struct JumpRingMask<3> { static constexpr uint32_t value = 0x09249249u; };   // a bit every R rows
