@@ -68,8 +68,8 @@ struct Ray {
     float voxel_color[3], color_accumulator[4];   // voxel_color.w is 0 from start to end in the reference (:684 "-= 0.0f")
     float fog_distance;
     bool shadow_ray, written;            // (as bools they live in scalar masks; packed into `flags` they cost VGPRs)
+    long pix0;                           // index of the wave's first pixel in the viewport / image / hit buffers (wave-uniform: cold_pixel_index)
     int flags;                           // kFlag* bits 0-3, kFlagHasHit, face_mask of the primary hit in bits 8-10
-    long pix;                            // index of the pixel in the viewport / image / hit buffers
     // the first strike (primary hit): what the light block needs to run again for a further light
     int kvx, kvy, kvz;                   // the solid voxel
     float kfx, kfy, kfz;                 // face_position
@@ -79,10 +79,12 @@ struct Ray {
     float hpx, hpy, hpz;                 // hit_pos of the last redirect (read by the node-exit jump kernel only)
 };
 
+__device__ __forceinline__ int cold_uniform(int v);                            // (below, with block_pixel)
+__device__ __forceinline__ long cold_pixel_index(const RaycastParams &p, long pix0);
+
 // :276-323 + the frame-constant bias of :342-354.  Returns false for the
 // zero-component early return (:293-294): nothing is written for that pixel.
 __device__ __forceinline__ bool ray_setup(Ray &r, const RaycastParams &p, long pix) {
-    r.pix = pix;
     r.flags = 0;
     r.written = false;
     r.distance_traveled = 0;
@@ -231,7 +233,7 @@ __device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastP
     // the primary hit goes straight into the pixel's hit record (it would otherwise sit in five registers until the
     // ray has finished); its face mask rides in the flags word
     if (!(r.flags & kFlagHasHit) && !r.shadow_ray) {
-        if (p.hits) reinterpret_cast<int4 *>(p.hits)[2 * r.pix] = make_int4(r.vx, r.vy, r.vz, voxel_data);
+        if (p.hits) reinterpret_cast<int4 *>(p.hits)[2 * cold_pixel_index(p, r.pix0)] = make_int4(r.vx, r.vy, r.vz, voxel_data);
         r.flags |= kFlagHasHit | ((r.fmx | (r.fmy << 1) | (r.fmz << 2)) << 8);
     }
 
@@ -243,8 +245,9 @@ __device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastP
 
     const bool mirror = (voxel_data == 6);
     // :652-656 / :684-688  tile (5,0) halved, tile (3,4) quartered
-    int tx = (int)(tfx * (float)p.tiles_x) + (int)((mirror ? 3.0f : 5.0f) * (float)p.tiles_x);
-    int ty = (int)(tfy * (float)p.tiles_y) + (int)((mirror ? 4.0f : 0.0f) * (float)p.tiles_y);
+    const float tiles_x = (float)cold_uniform(p.tiles_x), tiles_y = (float)cold_uniform(p.tiles_y);
+    int tx = (int)(tfx * tiles_x) + (int)((mirror ? 3.0f : 5.0f) * tiles_x);
+    int ty = (int)(tfy * tiles_y) + (int)((mirror ? 4.0f : 0.0f) * tiles_y);
     tx = tx < 0 ? 0 : (tx >= p.atlas_w ? p.atlas_w - 1 : tx);                 // undefined in OpenCL: clamp
     ty = ty < 0 ? 0 : (ty >= p.atlas_h ? p.atlas_h - 1 : ty);
     const uchar4 t8 = reinterpret_cast<const uchar4 *>(p.atlas)[(long)tx + (long)p.atlas_w * ty];
@@ -285,7 +288,8 @@ __device__ __forceinline__ bool hit_block(Ray &r, int voxel_data, const RaycastP
 }
 
 // :716-721 + the hit record
-__device__ __forceinline__ void ray_finish(Ray &r, const RaycastParams &p, long pix, unsigned c_desc) {
+__device__ __forceinline__ void ray_finish(Ray &r, const RaycastParams &p, unsigned c_desc) {
+    const long pix = cold_pixel_index(p, r.pix0);
     if (r.written) {
         const float k = 1.0f - max_cl(r.fog_distance / 700.0f, 0.0f);         // :716
         reinterpret_cast<float4 *>(p.image)[pix] =
@@ -326,6 +330,26 @@ __device__ __forceinline__ void block_pixel(const RaycastParams &p, int &px, int
     py = tile_y * kTileH + lane / kTileW;
     // row of this pixel in the viewport / image / hit buffers: the image row, or its position among this rank's rows
     buffer_row = p.row_sliced ? local_ty * kTileH + lane / kTileW : py;
+}
+
+// Values the COLD code needs (hit block, epilogue) and the step loop does not: computed where they are used, behind an empty
+// asm the optimiser cannot move code across -- hoisted out of the round loop they sit in registers the loop needs, i.e. in
+// scratch (the pixel index and the hit-record offset took 16 B per lane, two wave-uniform floats another 8; a scratch byte is
+// written to HBM once per wave whether it is read again or not).  The pixel index comes back from the index of the wave's
+// first pixel (wave-uniform: scalar registers) and the lane number: a wave is one kTileW x kTileH tile.
+__device__ __forceinline__ int cold_uniform(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ long wave_first_pixel(long pix) {                  // call with the whole wave active
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)pix), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(pix >> 32));
+    return (long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long cold_pixel_index(const RaycastParams &p, long pix0) {
+    int lane = (int)threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    lane &= 63;
+    return pix0 + (long)((lane & (kTileW - 1)) + p.width * (lane / kTileW));
 }
 
 // per-block counter partials (no global atomics): wave shuffle reduce, LDS, one row per block

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
     const long pix = (long)px + (long)p.width * brow;
 
     Ray r;
+    r.pix0 = wave_first_pixel(pix);
     unsigned c_primary = 0, c_desc = 0, c_unwritten = 0, c_steps = 0;
     int mode = jDone;
     auto ended = [&]() -> int { return (kMulti && more_lights(r, p)) ? jRelight : jDone; };
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
             c_tex = r.counts & 0xffu; c_shadow = (r.counts >> 8) & 0xffu;
             if (!r.written) c_unwritten = 1;
         }
-        ray_finish(r, p, pix, c_desc);
+        ray_finish(r, p, c_desc);
     }
 #ifdef VRC_SCHED_STATS
     atomicAdd(&block_ctr[kCtrWaveIters], (unsigned long long)s_rounds);

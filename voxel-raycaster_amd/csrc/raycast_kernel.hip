@@ -32,6 +32,8 @@
 //     mapping (block_pixel) gives every XCD the same sky/ground mix.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "exact_jump.hpp"
 #include "raycast_common.hpp"
 #include "safe_run.hpp"
@@ -68,9 +70,10 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
     block_pixel(p, px, py, brow);
     unsigned c_primary = 0, c_desc = 0, c_map = 0, c_steps = 0, c_unwritten = 0, c_tex = 0, c_shadow = 0;
 
+    const long pix = (long)px + (long)p.width * brow;
+    Ray r;
+    r.pix0 = wave_first_pixel(pix);
     if (px < p.width && py < p.height) {
-        const long pix = (long)px + (long)p.width * brow;
-        Ray r;
         if (!ray_setup(r, p, pix)) {
             c_unwritten = 1;
         } else {
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
             if (!r.written) c_unwritten = 1;
             c_tex = r.counts & 0xffu; c_shadow = (r.counts >> 8) & 0xffu;
         }
-        ray_finish(r, p, pix, c_desc);
+        ray_finish(r, p, c_desc);
     }
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, c_map, c_steps, c_unwritten};
     publish_counters(p, block_ctr, vals);
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     const long pix = (long)px + (long)p.width * brow;
 
     Ray r;
+    r.pix0 = wave_first_pixel(pix);
     unsigned c_primary = 0, c_desc = 0, c_unwritten = 0, broke = 0;
     int mode = kDone, mat = 5;
     bool t_unsafe = true;                                 // see arith_mask below
@@ -748,7 +752,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             c_tex = r.counts & 0xffu; c_shadow = (r.counts >> 8) & 0xffu;
             if (!r.written) c_unwritten = 1;
         }
-        ray_finish(r, p, pix, c_desc);
+        ray_finish(r, p, c_desc);
     }
 #ifdef VRC_SCHED_STATS
     if (w_iters) atomicAdd(&block_ctr[kCtrWaveIters], (unsigned long long)w_iters);
@@ -908,6 +912,8 @@ bool jump_tables_in_lds(const RaycastParams &p) {
     if (p.jump_tables_lds == 0) return false;
     if (p.jump_tables_lds == 1) return true;
     const size_t lds = svo_stack_bytes(p) + kLdsTabBytes;
+    static std::mutex guard;                             // (handles of several host threads may ask at the same time)
+    std::lock_guard<std::mutex> lock(guard);
     static size_t cached_lds = ~(size_t)0;
     static bool cached = false;
     if (cached_lds != lds) {
@@ -928,7 +934,7 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
     if (p.svo && p.stepping_mode == 1) return launch_raycast_jump(p, stream);
     if (p.svo) {
         const bool jump = p.jump_min_run < kJumpOff, multi = p.light_count > 1;
-        const bool lds_tab = jump && jump_tables_in_lds(p);
+        const bool lds_tab = jump && p.jump_tables_lds == 1;      // (vrc_api.cpp has resolved the setting to 0 / 1 with jump_tables_in_lds)
         const size_t lds = svo_stack_bytes(p) + (lds_tab ? kLdsTabBytes : 0);
         const bool tuned = (!jump || p.jump_min_run == (lds_tab ? kDefaultJumpMinRunLds : kDefaultJumpMinRun)) &&
                            p.widen_nodes != 0 && p.arith_mask != 0 && p.safe_run != 0 && p.single_step != 0 &&

@@ -1017,6 +1017,7 @@ int compute_async_one(vrc_caster *h) {
     // fit at full occupancy: depth 12)
     p.jump_tables_lds = (int32_t)std::min<int64_t>(2, std::max<int64_t>(0, setting_or(h, "jump_tables_lds", 2)));
     const bool tables_in_lds = vrc::jump_tables_in_lds(p);
+    p.jump_tables_lds = tables_in_lds ? 1 : 0;                     // resolved once, here: the launch takes it as it is
     p.jump_min_run = (int32_t)std::min<int64_t>(vrc::kJumpOff, std::max<int64_t>(1, setting_or(h, "jump_min_run",
                                     p.log2_dim >= vrc::kDefaultJumpMinDepth ? (tables_in_lds ? vrc::kDefaultJumpMinRunLds : vrc::kDefaultJumpMinRun)
                                                                             : vrc::kJumpOff)));
