@@ -341,6 +341,13 @@ __device__ __forceinline__ int cold_uniform(int v) {
     asm volatile("" : "+s"(v));
     return v;
 }
+// threadIdx.x again after the round loop, from the wave's index in the block (scalar: readfirstlane(threadIdx.x >> 6) taken at the
+// start) and the lane number
+__device__ __forceinline__ int cold_thread_index(int wave_in_block) {
+    unsigned zero = 0;
+    asm volatile("" : "+v"(zero));
+    return wave_in_block * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+}
 __device__ __forceinline__ long wave_first_pixel(long pix) {                  // call with the whole wave active
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)pix), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(pix >> 32));
     return (long)(((unsigned long long)hi << 32) | lo);
@@ -354,8 +361,8 @@ __device__ __forceinline__ long cold_pixel_index(const RaycastParams &p, long pi
 
 // per-block counter partials (no global atomics): wave shuffle reduce, LDS, one row per block
 __device__ __forceinline__ void publish_counters(const RaycastParams &p, unsigned long long *block_ctr,
-                                                 const unsigned (&vals)[7]) {
-    const int lane = threadIdx.x & 63;
+                                                 const unsigned (&vals)[7], int thread) {
+    const int lane = thread & 63;
 #pragma unroll
     for (int k = 0; k < 7; k++) {
         unsigned long long v = vals[k];
@@ -364,7 +371,7 @@ __device__ __forceinline__ void publish_counters(const RaycastParams &p, unsigne
         if (lane == 0 && v) atomicAdd(&block_ctr[k], v);
     }
     __syncthreads();
-    if (threadIdx.x < kCtrCount) p.counters[(long)blockIdx.x * kCtrCount + threadIdx.x] = block_ctr[threadIdx.x];
+    if (thread < kCtrCount) p.counters[(long)blockIdx.x * kCtrCount + thread] = block_ctr[thread];
 }
 
 }  // namespace vrc

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kBlockThreads, VRC_JUMP_MIN_BLOCKS) void raycast_ju
     atomicAdd(&block_ctr[kCtrShadeLanes], (unsigned long long)s_dlanes);
 #endif
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
-    publish_counters(p, block_ctr, vals);
+    publish_counters(p, block_ctr, vals, (int)threadIdx.x);
 }
 
 hipError_t launch_raycast_jump(const RaycastParams &p, hipStream_t stream) {

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlockThreads) void raycast_array_kernel(const Rayc
         ray_finish(r, p, c_desc);
     }
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, c_map, c_steps, c_unwritten};
-    publish_counters(p, block_ctr, vals);
+    publish_counters(p, block_ctr, vals, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     __shared__ unsigned long long block_ctr[kCtrCount];
     __shared__ int s_jump_slot;
     const int tid = threadIdx.x;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the epilogue rebuilds the thread index from it)
     if (tid < kCtrCount) block_ctr[tid] = 0;
     if (kLdsTab) {
         if (tid == 0) s_jump_slot = 0;
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
 
     Ray r;
     r.pix0 = wave_first_pixel(pix);
-    unsigned c_primary = 0, c_desc = 0, c_unwritten = 0, broke = 0;
+    r.flags = 0;                                          // (kFlagPrimary / kFlagUnwritten / kFlagBroke live here too)
+    unsigned c_desc = 0;
     int mode = kDone, mat = 5;
     bool t_unsafe = true;                                 // see arith_mask below
     int steps_base = 0;                                   // iterations of the segments before the last reset (kMulti)
@@ -326,9 +328,9 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
 
     if (in_image) {
         if (!ray_setup(r, p, pix)) {
-            c_unwritten = 1;
+            r.flags |= kFlagUnwritten;
         } else {
-            c_primary = 1;
+            r.flags |= kFlagPrimary;
             const uint64_t d = descriptors[p.root_index];
             c_desc = 1;
             root_entry = make_entry(descriptors, p.root_index, d);
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                 r.fmx = (int)fxf; r.fmy = (int)fyf; r.fmz = (int)fzf;
                 if (r.vx >= p.map_dim[0] || r.vy >= p.map_dim[1] || r.vz >= p.map_dim[2] || r.vx < 0 || r.vy < 0 || r.vz < 0) {
                     oob_exit(r);                          // :563-568
-                    broke = 1;
+                    r.flags |= kFlagBroke;
                     mode = ended();
                 } else {
                     const int b = locate(r.vx, r.vy, r.vz);
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                         mat = solid_material(r.vx, r.vy, r.vz);
                         if ((mat == 5 || mat == 6) && r.shadow_ray) {   // :575, :707-710
                             shadow_hit(r);
-                            broke = 1;
+                            r.flags |= kFlagBroke;
                             mode = ended();
                         } else if (mat == 5 || mat == 6) {
                             mode = kShade;                // the hit block is deferred
@@ -702,8 +704,8 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                 } else {
                     restart_from(r, strike_pos(r));
                     t_unsafe = true;
-                    steps_base += r.distance_traveled + (int)broke - (r.kdist + 1);
-                    broke = 0;
+                    steps_base += r.distance_traveled + ((r.flags >> kFlagBrokeShift) & 1) - (r.kdist + 1);
+                    r.flags &= ~kFlagBroke;
                     enter_single();
                     jrows = 0;                            // delta_t changed: the table of exact_jump.hpp is stale
                     r.distance_traveled = r.kdist + 1;    // as if the strike iteration had just finished (:714)
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             VRC_STAT(w_sh_passes, 1); VRC_STAT(w_sh_lanes, __popcll(sh));
             if (mode == kShade) {
                 if (hit_block<kMulti>(r, mat, p)) {
-                    broke = 1;
+                    r.flags |= kFlagBroke;
                     mode = ended();
                 } else {
                     enter_single();
@@ -741,14 +743,17 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         VRC_TICK(6);
     }
 
-    if (rounds_left < 0 && (tid & 63) == 0) {
+    const int tid_end = cold_thread_index(wave_in_block);  // threadIdx.x, without a register through the round loop
+    if (rounds_left < 0 && (tid_end & 63) == 0) {
         atomicAdd(&block_ctr[kCtrWatchdog], 1ULL);
         if (p.watchdog_flag) __hip_atomic_store(p.watchdog_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    unsigned c_steps = 0, c_tex = 0, c_shadow = 0;
+    unsigned c_steps = 0, c_tex = 0, c_shadow = 0, c_primary = 0, c_unwritten = 0;
     if (in_image) {
+        c_primary = (r.flags & kFlagPrimary) ? 1u : 0u;
+        c_unwritten = (r.flags & kFlagUnwritten) ? 1u : 0u;
         if (c_primary) {
-            c_steps = (unsigned)(steps_base + r.distance_traveled) + broke;
+            c_steps = (unsigned)(steps_base + r.distance_traveled) + (unsigned)((r.flags >> kFlagBrokeShift) & 1);
             c_tex = r.counts & 0xffu; c_shadow = (r.counts >> 8) & 0xffu;
             if (!r.written) c_unwritten = 1;
         }
@@ -768,15 +773,15 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
 #ifdef VRC_TIME_STATS
     {
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();
-        if ((tid & 63) == 0) {
+        if ((tid_end & 63) == 0) {
             t_acc[8] = now_ - t_begin;
             for (int k = 0; k < 9; k++) atomicAdd(&g_time_stats[k], t_acc[k]);
         }
     }
 #endif
     const unsigned vals[7] = {c_primary, c_shadow, c_desc, c_tex, 0u, c_steps, c_unwritten};
-    publish_counters(p, block_ctr, vals);                 // (a __syncthreads inside: every wave of the block is through with its tables)
-    if (kJump && !kLdsTab && tid == 0 && s_jump_slot >= 0) atomicExch(&p.jump_slots[s_jump_slot], 0u);
+    publish_counters(p, block_ctr, vals, tid_end);        // (a __syncthreads inside: every wave of the block is through with its tables)
+    if (kJump && !kLdsTab && tid_end == 0 && s_jump_slot >= 0) atomicExch(&p.jump_slots[s_jump_slot], 0u);
 }
 
 __global__ void reduce_counters_kernel(const unsigned long long *partials, int nblocks, unsigned long long *out) {

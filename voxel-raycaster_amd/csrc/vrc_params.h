@@ -64,6 +64,9 @@ constexpr int coarse_level_for_depth(int n) { return n >= 5 ? (n - 2 < kCoarseMa
 // hit-record flag bits (include/vrc.h VRC_HIT_FLAG_*)
 constexpr int kFlagWritten = 1, kFlagShadowCast = 2, kFlagShadowHit = 4, kFlagOob = 8;
 constexpr int kFlagHasHit = 0x800;     // internal: the primary hit has been recorded (bits above 7 never leave the kernels)
+// internal, SVO kernel: what the counters need at the end of the ray, kept in the flags word instead of a register each --
+// the pixel cast a primary ray, the pixel stays unwritten (:293-294), the last segment ended by a break (one more iteration)
+constexpr int kFlagPrimary = 0x1000, kFlagUnwritten = 0x2000, kFlagBroke = 0x4000, kFlagBrokeShift = 14;
 
 // counters[] slots (device, uint64)
 enum CounterSlot {
