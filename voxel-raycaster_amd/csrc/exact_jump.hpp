@@ -315,19 +315,19 @@ VRC_HD void jump_rows_build(bool want, bool live, uint32_t &rows, float tx, floa
         need &= ~rows;
     }
 }
+// The packed entry of (pair, binade e), 0 for a row the table does not hold ("no entry").  The load is unconditional -- the ring
+// slot row % R always exists -- and the dword stays packed until pair_ties() needs it: a guarded load with the decode right behind
+// it made every jump wait for three LDS round trips one after the other before its arithmetic started.  (A scheduling barrier
+// behind the three loads, so that none is sunk to its use: headline the same, the multi-light instances 3 % slower.)
 template <int R = kJumpRing>
-VRC_HD JumpEntry jump_table_entry(const uint32_t *tab, int stride, uint32_t rows, int pair, int32_t e) {
+VRC_HD uint32_t jump_table_word(const uint32_t *tab, int stride, uint32_t rows, int pair, int32_t e) {
     const uint32_t row = (uint32_t)(e - kJumpFirstBinade);
     const bool have = row < (uint32_t)kJumpBinades && ((rows >> (row & 31u)) & 1u);
-    JumpEntry en;
-    en.s = 0; en.g = 0;                                           // a row the table does not hold: "no entry"
 #ifdef VRC_JUMP_FAKE_TABLE   // (timing experiment only: no load, wrong tie counts)
-    if (have) { en.s = 12345 + pair; en.g = 1; }
-    return en;
+    return have ? (uint32_t)(12345 + pair) | (1u << 24) : 0u;
 #endif
-    // (the decode sits outside the `have` branch: its large-gcd half is behind a vote of the whole wave)
-    const uint32_t d = have ? tab[(3 * (int)(row % (uint32_t)R) + pair) * stride] : 0u;
-    return jump_entry_unpack(d);
+    const uint32_t d = tab[(3 * (int)(row % (uint32_t)R) + pair) * stride];
+    return have ? d : 0u;
 }
 
 // One regular axis pair in a common binade: the consumed events are Ma + i*ia (0 <= i < ma) and Mb + j*ib (0 <= j < mb),
@@ -390,7 +390,8 @@ VRC_HD PairTies pair_count(const PairProbe &p, int32_t Ma, int32_t ia, int32_t m
     }
     return out;
 }
-VRC_HD PairTies pair_ties(bool active, JumpEntry entry, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
+VRC_HD PairTies pair_ties(bool active, uint32_t word, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
+    JumpEntry entry = jump_entry_unpack(word);                    // (its large-gcd half is behind a vote of the whole wave)
     const bool solve = active && entry.g == 0;                    // no entry: below t = 128, beyond the table, evicted
 #if defined(VRC_SCHED_STATS) && defined(__HIP_DEVICE_COMPILE__)
     if (solve) atomicAdd(&g_jump_private_solves[0], 1ULL);
@@ -438,7 +439,9 @@ VRC_HD JumpAxis jump_axis(float t, float d, int32_t n) {
     // does, that value is the axis' bound E; if not, E is the LARGEST FLOAT OF THE BINADE -- not an event of the axis, only a bound:
     // every event of the axis up to it is consumed (jump_count gets their number by its one division) and the axis' next event
     // lies in the next binade, beyond every value the stretch consumes.
-    const uint32_t mant = (uint32_t)a.tb & 0x7fffffu, steps = (uint32_t)(n - 1), uinc = reg ? (uint32_t)a.inc : 64u;
+    // (a frozen axis takes no step: lo = 0, the test passes and E = t, c = 0 come out of the same selects -- written as nested
+    // conditionals the compiler made three exec-masked branches per axis out of them)
+    const uint32_t mant = (uint32_t)a.tb & 0x7fffffu, steps = reg ? (uint32_t)(n - 1) : 0u, uinc = reg ? (uint32_t)a.inc : 64u;
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t lo = __umul24(steps, uinc), hi = __umulhi(steps, uinc);
 #else
@@ -447,8 +450,8 @@ VRC_HD JumpAxis jump_axis(float t, float d, int32_t n) {
 #endif
     const bool fits = hi == 0u && lo <= 0x7fffffu - mant;
     a.reg = reg;
-    a.c = (reg && fits) ? n - 1 : (reg ? -1 : 0);                 // -1: E is the binade's end, the event count comes from jump_count's division
-    a.E = reg ? (fits ? u2f((uint32_t)a.tb + lo) : u2f(((uint32_t)a.tb & 0xff800000u) | 0x7fffffu)) : t;
+    a.c = fits ? (int32_t)steps : -1;                             // -1: E is the binade's end, the event count comes from jump_count's division
+    a.E = u2f(fits ? (uint32_t)a.tb + lo : ((uint32_t)a.tb | 0x7fffffu));
 #else
     // steps that stay inside the binade: floor((2^24 - 1 - M) / inc), exact (a short estimate would cost a whole extra jump)
     const int32_t room = floordiv_small(0x7fffff - (a.tb & 0x7fffff), reg ? a.inc : 64);
@@ -464,7 +467,7 @@ VRC_HD JumpAxis jump_axis(float t, float d, int32_t n) {
 VRC_HD void jump_count(JumpAxis &a, float t, float X) {
     const int32_t diff = (int32_t)f2u(X) - a.tb;                  // meaningful for t <= X < E: 0 <= diff < c*inc < 2^24
 #ifndef VRC_JUMP_ROOM
-    const bool mid = a.reg && X >= t && (X < a.E || a.c < 0);     // (X == E with E the binade's end: counted, not known)
+    const bool mid = a.reg & (X >= t) & ((X < a.E) | (a.c < 0));  // (X == E with E the binade's end: counted, not known; no short circuits: they compile to branches)
     const int32_t k = floordiv_small(mid ? diff : 0, mid ? a.inc : 64);
     int32_t m = mid ? k + 1 : a.c + 1;
 #else
@@ -474,7 +477,7 @@ VRC_HD void jump_count(JumpAxis &a, float t, float X) {
 #endif
     m = (X >= t) ? m : 0;
     a.m = m;
-    a.last = (a.reg && m > 0) ? u2f((uint32_t)(a.tb + mul24(m - 1, a.inc))) : t;
+    a.last = u2f((uint32_t)(a.tb + mul24((a.reg & (m > 0)) ? m - 1 : 0, a.inc)));   // (t itself when nothing was consumed)
     a.hitX = m > 0 && a.last == X;
 }
 
@@ -498,9 +501,9 @@ VRC_HD JumpOut stretch_jump(float &tx, float &ty, float &tz, float dx, float dy,
                             int32_t &nz, int32_t left, const uint32_t *tab, int stride, uint32_t rows) {
     // the table dwords first: their addresses need the exponents only, and the loads have the whole decode to arrive
     const int32_t ex0 = (int32_t)(f2u(tx) >> 23), ey0 = (int32_t)(f2u(ty) >> 23), ez0 = (int32_t)(f2u(tz) >> 23);
-    const JumpEntry txy = jump_table_entry<R>(tab, stride, ex0 == ey0 ? rows : 0u, 0, ex0);
-    const JumpEntry txz = jump_table_entry<R>(tab, stride, ex0 == ez0 ? rows : 0u, 1, ex0);
-    const JumpEntry tyz = jump_table_entry<R>(tab, stride, ey0 == ez0 ? rows : 0u, 2, ey0);
+    const uint32_t txy = jump_table_word<R>(tab, stride, ex0 == ey0 ? rows : 0u, 0, ex0);
+    const uint32_t txz = jump_table_word<R>(tab, stride, ex0 == ez0 ? rows : 0u, 1, ex0);
+    const uint32_t tyz = jump_table_word<R>(tab, stride, ey0 == ez0 ? rows : 0u, 2, ey0);
     JumpAxis ax = jump_axis(tx, dx, nx), ay = jump_axis(ty, dy, ny), az = jump_axis(tz, dz, nz);
     float X = ax.E < ay.E ? ax.E : ay.E;
     X = X < az.E ? X : az.E;
