@@ -37,7 +37,7 @@ enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4, jT
 constexpr int kCoarseBrickLog2 = VRC_COARSE_BRICK;
 __device__ __forceinline__ uint64_t coarse_index(unsigned cx, unsigned cy, unsigned cz, int lc) {
     constexpr unsigned k = kCoarseBrickLog2, m = (1u << k) - 1u;
-    if (k == 0 || lc < (int)k) return (uint64_t)cx | ((uint64_t)cy << lc) | ((uint64_t)cz << (2 * lc));
+    if (k == 0 || lc < (int)k) return cx | (cy << lc) | (cz << (2 * lc));   // (32 bits: lc <= 10, vrc_api.cpp)
     const int lb = lc - (int)k;                            // bricks per axis = 2^lb
     const uint64_t brick = (uint64_t)(cx >> k) | ((uint64_t)(cy >> k) << lb) | ((uint64_t)(cz >> k) << (2 * lb));
     return (brick << (3 * k)) | (cx & m) | ((cy & m) << k) | ((cz & m) << (2 * k));

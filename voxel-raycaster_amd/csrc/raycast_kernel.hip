@@ -236,7 +236,8 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             // node that holds both voxels, or where the cursor already sits) and made t - a descents from there
             int a = n - (32 - __clz((int)diff));          // (diff == 0: n)
             a = a < top ? a : top;
-            const uint64_t e = p.coarse[(uint64_t)(unsigned)(x >> csh) | ((uint64_t)(unsigned)(y >> csh) << lc) | ((uint64_t)(unsigned)(z >> csh) << (2 * lc))];
+            // (the cell index in 32 bits: the table's level is at most 10 -- vrc_api.cpp -- so it has at most 30)
+            const uint64_t e = p.coarse[(unsigned)(x >> csh) | ((unsigned)(y >> csh) << lc) | ((unsigned)(z >> csh) << (2 * lc))];
             cur = e & ((1ULL << kCoarseLevelShift) - 1ULL);
             top = (int)(e >> kCoarseLevelShift);
             c_desc += (unsigned)(top - a);
