@@ -476,7 +476,12 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         bool deep = false;                                // still far from the node face after the safe run
         if (arith_mask && use_safe && safe_cap >= kSafeUnroll) {
             SafeGate gate;
-            if (mode == kStep && r.max_distance - r.distance_traveled >= safe_cap) {
+            if (kJump) {                                  // (branch-free form, see make_gate)
+                const bool steps = (mode == kStep) & (r.max_distance - r.distance_traveled >= safe_cap);
+                const float T = fminf(fminf(safe_threshold(r.itx, r.dtx, nx), safe_threshold(r.ity, r.dty, ny)),
+                                      safe_threshold(r.itz, r.dtz, nz));
+                gate = make_gate<true>(steps ? T : -1.0f, fminf(fminf(r.itx, r.ity), r.itz), safe_limit, fminf(fminf(r.dtx, r.dty), r.dtz));
+            } else if (mode == kStep && r.max_distance - r.distance_traveled >= safe_cap) {
                 const float T = fminf(fminf(safe_threshold(r.itx, r.dtx, nx), safe_threshold(r.ity, r.dty, ny)),
                                       safe_threshold(r.itz, r.dtz, nz));
                 gate = make_gate(T, fminf(fminf(r.itx, r.ity), r.itz), safe_limit, fminf(fminf(r.dtx, r.dty), r.dtz));

@@ -81,9 +81,19 @@ struct SafeGate { float neg_b1 = 0.0f, tb1 = -1.0f; bool open = false; };
 
 // min_dt: the smallest delta_t of the ray; the recovery bound needs delta_t >= 1 (|ray_dir| <= 1: the reference's rays
 // are normalised, a host-supplied ray table need not be)
+// kSelects: no branches -- every lane computes, the tests pick (a NaN fails them all).  The jump instances of the SVO kernel are
+// 0.4-1.3 % faster with it (the nested conditions compile to three exec-masked branches per round), the plain instance 1.4 % slower.
+template <bool kSelects = false>
 VRC_SR SafeGate make_gate(float T, float min_t, float t_limit, float min_dt) {
     SafeGate g;
-    if (T >= 0x1p-60f && T < t_limit && min_t < T && min_dt >= 0.999f) {
+    if (kSelects) {
+        union { float f; uint32_t u; } c;
+        c.f = T;
+        c.u = (278u - (c.u >> 23)) << 23;          // 2^(24-e) for 2^e <= T < 2^(e+1)
+        g.open = (T >= 0x1p-60f) & (T < t_limit) & (min_t < T) & (min_dt >= 0.999f);
+        g.neg_b1 = g.open ? -c.f : 0.0f;
+        g.tb1 = g.open ? T * c.f : -1.0f;
+    } else if (T >= 0x1p-60f && T < t_limit && min_t < T && min_dt >= 0.999f) {
         union { float f; uint32_t u; } c;
         c.f = T;
         c.u = (278u - (c.u >> 23)) << 23;          // 2^(24-e) for 2^e <= T < 2^(e+1)
