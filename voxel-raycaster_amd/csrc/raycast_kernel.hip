@@ -474,6 +474,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         // steps): no exec masking, scalar loop control, kSafeUnroll iterations per loop trip (the vote and the scalar
         // branch are not free: 2 -> 4 -> 8 -> 16 -> 32 iterations per trip measured 3.30 -> 3.11 -> 3.09 -> 3.03 -> 3.14 ms).
         bool deep = false;                                // still far from the node face after the safe run
+        constexpr int kSafeUnroll = kJump ? kSafeUnrollJump : kSafeUnrollPlain;
         if (arith_mask && use_safe && safe_cap >= kSafeUnroll) {
             SafeGate gate;
             if (kJump) {                                  // (branch-free form, see make_gate)

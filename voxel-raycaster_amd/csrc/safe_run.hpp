@@ -37,7 +37,13 @@ constexpr int kSafeMaxSteps = 256;     // most iterations per safe run the setti
 #ifndef VRC_SAFE_UNROLL
 #define VRC_SAFE_UNROLL 16
 #endif
-constexpr int kSafeUnroll = VRC_SAFE_UNROLL;   // iterations per loop trip of a safe run (setting safe_steps is rounded down to it)
+#ifndef VRC_SAFE_UNROLL_PLAIN
+#define VRC_SAFE_UNROLL_PLAIN 8
+#endif
+// iterations per loop trip of a safe run (setting safe_steps is rounded down to it): the jump instances run ONE trip of 16 per round;
+// the plain instances (trees below depth 12) up to four trips of 8 with the exit vote between them (depth 10: 0.369 -> 0.349 ms;
+// the same in the jump instances: 1.91 -> 1.95 ms)
+constexpr int kSafeUnrollJump = VRC_SAFE_UNROLL, kSafeUnrollPlain = VRC_SAFE_UNROLL_PLAIN;
 
 // largest threshold T a safe run of at most `steps` iterations may use (see the recovery bound above)
 VRC_SR float safe_t_limit(int steps) {
