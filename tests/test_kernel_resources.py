@@ -1,0 +1,78 @@
+"""Register / scratch budget of the built kernels, read from the code objects inside voxel-raycaster_amd/libvrc.so
+(llvm-objdump --offloading + llvm-readelf --notes: no GPU, no recompile).  Guards what round 4 paid for: the headline
+instance of the SVO kernel keeps its 5 waves per SIMD (96 VGPRs) with no more than 40 B of scratch per lane -- every
+scratch byte is written to HBM once per wave, and at 52 B the launch wrote 5.1 x the frame (profiles/HISTORY.md)."""
+import os, re, shutil, subprocess, tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def kernel_table():
+    lib = os.path.join(ROOT, "voxel-raycaster_amd", "libvrc.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+        g.build()
+    tmp = tempfile.mkdtemp(prefix="vrc_co_")
+    try:
+        shutil.copy(lib, os.path.join(tmp, "libvrc.so"))
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "libvrc.so"], cwd=tmp, check=True, capture_output=True)
+        table = {}
+        for name in sorted(os.listdir(tmp)):
+            if "amdgcn" not in name:
+                continue
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, name)], capture_output=True, text=True).stdout
+            cur = None
+            for line in notes.splitlines():
+                m = re.match(r"\s+\.(name|private_segment_fixed_size|vgpr_count|sgpr_count):\s+(\S+)", line)
+                if not m:
+                    continue
+                if m.group(1) == "name":
+                    cur = table.setdefault(m.group(2), {})
+                elif cur is not None:
+                    cur[m.group(1)] = int(m.group(2))
+        return table
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(os.path.join(LLVM, "llvm-readelf")):
+        pytest.skip("no llvm-readelf in this image")
+    t = kernel_table()
+    assert t, "no gfx950 code object found in libvrc.so"
+    return t
+
+
+def svo(jump, multi, tuned, lds, coarse):
+    b = lambda v: "Lb1E" if v else "Lb0E"
+    return "_ZN3vrc18raycast_svo_kernelI" + b(jump) + b(multi) + b(tuned) + b(lds) + b(coarse) + "EEvNS_13RaycastParamsE"
+
+
+def test_headline_instance_budget(kernels):
+    k = kernels[svo(True, False, True, True, True)]
+    assert k["vgpr_count"] <= 96                       # 5 waves per SIMD
+    assert k["private_segment_fixed_size"] <= 40       # round 3: 76, round 4 before the ISA pass: 52, now 20
+
+
+def test_plain_instance_budget(kernels):
+    k = kernels[svo(False, False, True, False, True)]  # trees below depth 12 (BASELINE configs[0], configs[1])
+    assert k["vgpr_count"] <= 80                       # 6 waves per SIMD
+    assert k["private_segment_fixed_size"] <= 16
+
+
+def test_every_svo_instance_keeps_its_occupancy(kernels):
+    names = [n for n in kernels if n.startswith("_ZN3vrc18raycast_svo_kernelI")]
+    assert len(names) == 24                            # kJump x kMulti x kTuned x (tables in LDS | global | no jumps) x kCoarse
+    for n in names:
+        jump = n[len("_ZN3vrc18raycast_svo_kernelI"):].startswith("Lb1E")
+        assert kernels[n]["vgpr_count"] <= (96 if jump else 80), n
+
+
+def test_mode_b_budget(kernels):
+    k = kernels["_ZN3vrc19raycast_jump_kernelILb0ELb1EEEvNS_13RaycastParamsE"]
+    assert k["vgpr_count"] <= 64                       # 8 waves per SIMD
+    assert k["private_segment_fixed_size"] <= 48
