@@ -205,6 +205,13 @@ typedef struct vrc_memory {
 } vrc_memory;
 int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out);
 
+/* Self-check of the empty boxes the last frame was rendered with (setting empty_boxes; a derived structure like the coarse
+ * table, no counterpart in the reference: Octree.cpp never annotates empty space): `samples` pseudo-random (descriptor,
+ * child) pairs are drawn, for each empty child one voxel of its box is looked up in the tree.  *solid_voxels must come back
+ * 0.  build_seconds: device time of the boxes' construction.  Any out pointer may be NULL.                              */
+int vrc_empty_boxes_check(vrc_caster *h, uint64_t samples, uint64_t seed, uint64_t *boxes_sampled, uint64_t *solid_voxels,
+                          double *build_seconds);
+
 /* ---- output ------------------------------------------------------------ */
 
 /* CLCaster::draw (CLCaster.cpp:330-332) has no read-back; these replace it.

@@ -15,9 +15,13 @@ def oracle_frame(s, w, h, atlas, buf, root, trig, threads=8):
                        grid=s["grid"], max_distance=20, trig=trig, threads=threads)
 
 
-def compare(s, w, h, rec, oimg, ohits, octr, verbose=True, totals=None):
-    """Everything that depends only on the primary ray must be EQUAL; what follows the shadow redirect goes through the
-    OpenCL library's approximate normalize / fast_distance and is required to agree on nearly all pixels."""
+def compare(s, w, h, rec, oimg, ohits, octr, verbose=True, totals=None, strict=True):
+    """Everything that depends only on the primary ray must be EQUAL.  What follows the shadow redirect goes through the
+    OpenCL library's approximate normalize / fast_distance: on the FIXED scenes (strict, the default) the measured result
+    is asserted -- final step count and in-shadow flag equal on every shaded pixel, RGB within BASELINE's 1e-5 relative on
+    every shaded pixel; a random-pose soak (strict=False, or totals) keeps the loose floors, because a pose can put a
+    pixel where the library's 1-2 ulp decide a step count.
+    (oimg, ohits, octr) may come from the oracle or from libvrc.so: same layouts.)"""
     written = rec[..., 15] == 1
     # pixels the kernel returned from without writing (:293-294, :671-672, :694-695)
     assert np.array_equal(written, (ohits[..., 5] & 1) == 1), "written / unwritten pixels differ"
@@ -56,5 +60,10 @@ def compare(s, w, h, rec, oimg, ohits, octr, verbose=True, totals=None):
             totals["worst_rgb"] = max(totals.get("worst_rgb", 0.0), float(rel.max()))
             return
         assert shadow_same.all()
-        assert same_steps.mean() >= 0.995 and alpha_same.mean() >= 0.995
-        assert (rel.max(-1) <= 1e-4).mean() >= 0.995
+        if strict:
+            assert same_steps.all(), f"final step count differs on {int((~same_steps).sum())} shaded pixels"
+            assert alpha_same.all(), f"alpha differs on {int((~alpha_same).sum())} shaded pixels"
+            assert (rel.max(-1) <= 1e-5).all(), f"rgb beyond 1e-5 on {int((rel.max(-1) > 1e-5).sum())} shaded pixels (worst {float(rel.max()):.3g})"
+        else:
+            assert same_steps.mean() >= 0.995 and alpha_same.mean() >= 0.995
+            assert (rel.max(-1) <= 1e-4).mean() >= 0.995

@@ -132,6 +132,7 @@ SIGNATURES = {
     "vrc_pin_host_buffer": (C.c_int, [C.c_void_p, C.c_size_t]),
     "vrc_unpin_host_buffer": (C.c_int, [C.c_void_p]),
     "vrc_memory_usage": (C.c_int, [_H, C.c_int32, C.POINTER(Memory)]),
+    "vrc_empty_boxes_check": (C.c_int, [_H, C.c_uint64, C.c_uint64, _u64p, _u64p, C.POINTER(C.c_double)]),
     "vrc_scene_shell_terrain_ex": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(_u64p), _u64p, _u64p, _i32p]),
     "vrc_scene_shell_column": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _i32p, _i32p]),
     "vrc_build_shell_terrain": (C.c_int, [_H, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint32, C.c_uint64, _i32p, C.c_uint32,
@@ -427,6 +428,13 @@ class CLCaster:
         if not self._ok(lib.vrc_memory_usage(self._h, rank, C.byref(m))):
             raise VrcError(self.last_error())
         return m.as_dict()
+
+    def empty_boxes_check(self, samples: int = 1 << 20, seed: int = 1) -> dict:
+        """vrc_empty_boxes_check: sampled voxels of the empty boxes the last frame used, looked up in the tree."""
+        n, bad, sec = C.c_uint64(), C.c_uint64(), C.c_double()
+        if not self._ok(lib.vrc_empty_boxes_check(self._h, samples, seed, C.byref(n), C.byref(bad), C.byref(sec))):
+            raise VrcError(self.last_error())
+        return {"boxes_sampled": int(n.value), "solid_voxels": int(bad.value), "build_seconds": float(sec.value)}
 
     def build_shell_terrain(self, depth: int, seed: int = 1, thickness: int = 2, octave_floor: int = 2, count_only: bool = False,
                             validate_samples: int = 0, probe_xy: Optional[np.ndarray] = None):

@@ -1,0 +1,285 @@
+// empty_boxes.hip -- a derived acceleration structure for the SVO kernels: for every EMPTY child slot of every
+// descriptor, an axis-aligned box of voxels around that empty node that the tree says holds nothing.
+//
+// Why: the reference's working traversal (kernels/ray_caster_kernel.cl:555-570) tests one voxel per iteration; the SVO
+// kernel already steps through a whole empty octree node without memory (raycast_kernel.hip), but a ray that leaves or
+// approaches a surface climbs through the octree's levels -- nodes of 1, 1, 2, 2, 4, 4, ... voxels -- and pays a node event
+// for each (profiles/r03_run_length_histogram.txt: the events are spread evenly over run lengths 1 .. 1023).  The octree
+// node is only ONE empty box around a voxel; any other empty box serves the step loop equally well, because inside a box
+// the loop needs no occupancy at all -- the float recurrence and the iteration count are untouched, so frames stay
+// bit-identical.  Occupancy still comes from the descriptor array alone (Octree.h:89-94): the boxes are computed from it
+// here, on the device, like the coarse top table.
+//
+// Layout: boxes[8 * d + k] (uint32) belongs to child slot k = x | y<<1 | z<<2 of descriptor d; meaningful where that child is
+// not valid (empty).  Six 5-bit extents, in units of the node's own size s, by which the node is extended on each side:
+//   bits 0-4 -x, 5-9 -y, 10-14 -z, 15-19 +x, 20-24 +y, 25-29 +z;   code c -> c (c < 4), (4 | c & 3) << (c / 4 - 1) otherwise
+// (0, 1, 2, 3, 4 .. 7, 8, 10 .. 14, 16, 20 .. 28, 32 ... 448: two mantissa bits).  The kernel clamps the box to the map.
+// The cells of the coarse top table get a parallel word (box_aux): the box of the empty node a cell resolves to above the
+// table's level, or the index of the level-lc descriptor the descent continues from.
+//
+// Construction: every descriptor's position comes from a level-by-level sweep; then one thread per (descriptor, child)
+// grows the box greedily -- each side in turn by one code step, the new slab checked against the tree by a region query
+// (depth-first, pruned by the region) -- until every side is blocked or at the map's edge.  Any empty box is a correct
+// box; the greedy order only decides how good it is.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "vrc_params.h"
+
+namespace vrc {
+
+namespace {
+
+constexpr uint64_t kPosNone = ~0ULL;
+constexpr int kPosBits = 19;              // coordinates below 2^19; bits 57-61 hold the level
+constexpr int kPosLevelShift = 57;
+
+__device__ __forceinline__ uint64_t bx_entry(const uint64_t *__restrict__ descriptors, uint64_t index, uint64_t d) {
+    uint64_t base = index + (d & 0x7fffULL);
+    if (d & 0x8000ULL) base = descriptors[base];          // far pointer: the slot holds an absolute index
+    return (base << 16) | ((d >> 16) & 0xffffULL);        // bits 0-7 valid, 8-15 leaf, 16.. first child
+}
+
+__device__ __forceinline__ uint64_t pack_pos(int x, int y, int z, int level) {
+    return (uint64_t)(unsigned)x | ((uint64_t)(unsigned)y << kPosBits) | ((uint64_t)(unsigned)z << (2 * kPosBits)) | ((uint64_t)level << kPosLevelShift);
+}
+
+__global__ void box_fill_kernel(uint64_t *p, uint64_t n, uint64_t v) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// one level of the position sweep: descriptors of `level` hand their position down to their kept children
+__global__ void box_positions_kernel(const uint64_t *__restrict__ descriptors, uint64_t n_desc, int n, int level, uint64_t *__restrict__ pos) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_desc) return;
+    const uint64_t ps = pos[idx];
+    if (ps == kPosNone || (int)(ps >> kPosLevelShift) != level) return;
+    const int half = 1 << (n - level - 1);
+    if (half == 1) return;                                // the children are voxels
+    const uint64_t e = bx_entry(descriptors, idx, descriptors[idx]);
+    const unsigned valid = (unsigned)e & 0xffu, leaf = ((unsigned)e >> 8) & 0xffu;
+    const int x = (int)(ps & ((1u << kPosBits) - 1u)), y = (int)((ps >> kPosBits) & ((1u << kPosBits) - 1u)), z = (int)((ps >> (2 * kPosBits)) & ((1u << kPosBits) - 1u));
+    unsigned rank = 0;
+    for (int k = 0; k < 8; k++) {
+        if (!(valid & (1u << k))) continue;
+        if (!(leaf & (1u << k))) {
+            const uint64_t child = (e >> 16) + rank;
+            if (child < n_desc)
+                pos[child] = pack_pos(x + ((k & 1) ? half : 0), y + ((k & 2) ? half : 0), z + ((k & 4) ? half : 0), level + 1);
+        }
+        rank++;
+    }
+}
+
+__device__ __forceinline__ int box_decode(unsigned c) { return c < 4u ? (int)c : (int)((4u | (c & 3u)) << ((c >> 2) - 1u)); }
+
+// children of the node at (ox, oy, oz) with child size `half` that meet the region [lo, hi)
+__device__ __forceinline__ unsigned overlap_mask(int ox, int oy, int oz, int half, const int lo[3], const int hi[3]) {
+    unsigned m = 0xffu;
+    const int mx = ox + half, my = oy + half, mz = oz + half;
+    if (!(lo[0] < mx)) m &= 0xAAu;                        // low x half not touched
+    if (!(hi[0] > mx)) m &= 0x55u;
+    if (!(lo[1] < my)) m &= 0xCCu;
+    if (!(hi[1] > my)) m &= 0x33u;
+    if (!(lo[2] < mz)) m &= 0xF0u;
+    if (!(hi[2] > mz)) m &= 0x0Fu;
+    return m;
+}
+
+// Does the tree hold a solid voxel inside [lo, hi)?  (the region lies inside the map and is not empty)
+__device__ bool region_is_empty(const uint64_t *__restrict__ descriptors, uint64_t root_index, int n, const int lo[3], const int hi[3]) {
+    uint64_t st_entry[kMaxLevels];
+    int st_x[kMaxLevels], st_y[kMaxLevels], st_z[kMaxLevels];
+    unsigned st_todo[kMaxLevels];
+    int level = 0;
+    st_entry[0] = bx_entry(descriptors, root_index, descriptors[root_index]);
+    st_x[0] = st_y[0] = st_z[0] = 0;
+    st_todo[0] = overlap_mask(0, 0, 0, 1 << (n - 1), lo, hi) & (unsigned)st_entry[0] & 0xffu;
+    while (level >= 0) {
+        const unsigned todo = st_todo[level];
+        if (!todo) { level--; continue; }
+        const int k = __ffs((int)todo) - 1;
+        st_todo[level] = todo & (todo - 1u);
+        const uint64_t e = st_entry[level];
+        const int half = 1 << (n - level - 1);
+        if ((((unsigned)e >> 8) & (1u << k)) || half == 1) return false;      // a solid leaf / voxel that meets the region
+        const uint64_t child = (e >> 16) + (uint64_t)(__popc((unsigned)e & 0xffu & ((2u << k) - 1u)) - 1);
+        const uint64_t ce = bx_entry(descriptors, child, descriptors[child]);
+        const int cx = st_x[level] + ((k & 1) ? half : 0), cy = st_y[level] + ((k & 2) ? half : 0), cz = st_z[level] + ((k & 4) ? half : 0);
+        level++;
+        st_entry[level] = ce; st_x[level] = cx; st_y[level] = cy; st_z[level] = cz;
+        st_todo[level] = overlap_mask(cx, cy, cz, half >> 1, lo, hi) & (unsigned)ce & 0xffu;
+    }
+    return true;
+}
+
+__global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64_t n_desc, uint64_t root_index, int n,
+                                const uint64_t *__restrict__ pos, uint32_t *__restrict__ boxes) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t idx = t >> 3;
+    const int k = (int)(t & 7u);
+    if (idx >= n_desc) return;
+    const uint64_t ps = pos[idx];
+    uint32_t word = 0;
+    if (ps != kPosNone) {
+        const unsigned valid = (unsigned)(descriptors[idx] >> 16) & 0xffu;
+        if (!(valid & (1u << k))) {
+            const int level = (int)(ps >> kPosLevelShift);
+            const int b = n - level - 1, s = 1 << b, dim = 1 << n;
+            int lo[3], hi[3];
+            lo[0] = (int)(ps & ((1u << kPosBits) - 1u)) + ((k & 1) ? s : 0);
+            lo[1] = (int)((ps >> kPosBits) & ((1u << kPosBits) - 1u)) + ((k & 2) ? s : 0);
+            lo[2] = (int)((ps >> (2 * kPosBits)) & ((1u << kPosBits) - 1u)) + ((k & 4) ? s : 0);
+            for (int a = 0; a < 3; a++) hi[a] = lo[a] + s;
+            const int org_lo[3] = {lo[0], lo[1], lo[2]}, org_hi[3] = {hi[0], hi[1], hi[2]};
+            unsigned code[6] = {0, 0, 0, 0, 0, 0};          // -x -y -z +x +y +z
+            unsigned alive = 0x3fu;
+            // the sides in turn, z first (open sky above a terrain costs nothing to claim)
+            const int order[6] = {5, 2, 3, 0, 4, 1};
+            while (alive) {
+                for (int oi = 0; oi < 6; oi++) {
+                    const int side = order[oi];
+                    if (!(alive & (1u << side))) continue;
+                    const int a = side % 3;
+                    const bool positive = side >= 3;
+                    const unsigned next = code[side] + 1u;
+                    // the box already reaches the map's edge on this side, or the code is exhausted
+                    if (next > 31u || (positive ? hi[a] >= dim : lo[a] <= 0)) { alive &= ~(1u << side); continue; }
+                    const int ext = box_decode(next) << b;
+                    int slo[3] = {lo[0], lo[1], lo[2]}, shi[3] = {hi[0], hi[1], hi[2]};
+                    int new_edge;
+                    if (positive) { new_edge = org_hi[a] + ext; if (new_edge > dim) new_edge = dim; slo[a] = hi[a]; shi[a] = new_edge; }
+                    else { new_edge = org_lo[a] - ext; if (new_edge < 0) new_edge = 0; shi[a] = lo[a]; slo[a] = new_edge; }
+                    if (region_is_empty(descriptors, root_index, n, slo, shi)) {
+                        code[side] = next;
+                        if (positive) hi[a] = new_edge; else lo[a] = new_edge;
+                    } else {
+                        alive &= ~(1u << side);
+                    }
+                }
+            }
+            for (int side = 0; side < 6; side++) word |= code[side] << (5 * side);
+        }
+    }
+    boxes[t] = word;
+}
+
+// the coarse table's parallel word (see the header comment); same descent as coarse_build_kernel (raycast_jump_kernel.hip)
+__global__ void box_aux_kernel(const uint64_t *__restrict__ descriptors, uint64_t root_index, int n, int lc,
+                               const uint32_t *__restrict__ boxes, uint32_t *__restrict__ aux) {
+    const uint64_t cell = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;     // x fastest
+    if (cell >> (3 * lc)) return;
+    const int sh = n - lc;
+    const int x = (int)((cell & ((1u << lc) - 1u)) << sh), y = (int)(((cell >> lc) & ((1u << lc) - 1u)) << sh), z = (int)((cell >> (2 * lc)) << sh);
+    uint64_t own = root_index;
+    uint64_t cur = bx_entry(descriptors, root_index, descriptors[root_index]);
+    int top = 0;
+    uint32_t out = 0;
+    for (;;) {
+        if (top == lc) { out = (uint32_t)own; break; }
+        const int b = n - top - 1;
+        const int i = ((x >> b) & 1) | (((y >> b) & 1) << 1) | (((z >> b) & 1) << 2);
+        const unsigned masks = (unsigned)cur & 0xffffu, bit = 1u << i;
+        if (!(masks & bit)) { out = boxes[own * 8 + (uint64_t)i]; break; }     // empty above the table's level: its box
+        if ((masks >> 8) & bit) { out = 0; break; }                             // solid leaf
+        own = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
+        cur = bx_entry(descriptors, own, descriptors[own]);
+        top++;
+    }
+    aux[cell] = out;
+}
+
+// self-check: pseudo-random voxels inside the boxes must be empty in the tree (point query from the root)
+__device__ __forceinline__ uint64_t bx_mix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+__global__ void box_check_kernel(const uint64_t *__restrict__ descriptors, uint64_t n_desc, uint64_t root_index, int n,
+                                 const uint64_t *__restrict__ pos, const uint32_t *__restrict__ boxes, uint64_t samples, uint64_t seed,
+                                 unsigned long long *__restrict__ result) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= samples) return;
+    // a (descriptor, child) pair per sample; pairs that are no empty child slot are skipped
+    const uint64_t r0 = bx_mix(seed ^ t), r1 = bx_mix(r0), r2 = bx_mix(r1);
+    const uint64_t idx = r0 % n_desc;
+    const int k = (int)(r1 & 7u);
+    const uint64_t ps = pos[idx];
+    if (ps == kPosNone) return;
+    const unsigned valid = (unsigned)(descriptors[idx] >> 16) & 0xffu;
+    if (valid & (1u << k)) return;
+    const int level = (int)(ps >> kPosLevelShift), b = n - level - 1, s = 1 << b, dim = 1 << n;
+    int lo[3], hi[3];
+    lo[0] = (int)(ps & ((1u << kPosBits) - 1u)) + ((k & 1) ? s : 0);
+    lo[1] = (int)((ps >> kPosBits) & ((1u << kPosBits) - 1u)) + ((k & 2) ? s : 0);
+    lo[2] = (int)((ps >> (2 * kPosBits)) & ((1u << kPosBits) - 1u)) + ((k & 4) ? s : 0);
+    const uint32_t w = boxes[idx * 8 + (uint64_t)k];
+    for (int a = 0; a < 3; a++) {
+        hi[a] = lo[a] + s + (box_decode((w >> (15 + 5 * a)) & 31u) << b);
+        lo[a] -= box_decode((w >> (5 * a)) & 31u) << b;
+        if (lo[a] < 0) lo[a] = 0;
+        if (hi[a] > dim) hi[a] = dim;
+    }
+    atomicAdd(&result[0], 1ULL);
+    // a voxel of the box, biased toward its faces (every other sample lies on one)
+    int v[3];
+    for (int a = 0; a < 3; a++) v[a] = lo[a] + (int)((r2 >> (20 * a)) % (uint64_t)(hi[a] - lo[a]));
+    if (r1 & 8u) { const int a = (int)((r1 >> 4) % 3u); v[a] = (r1 & 64u) ? hi[a] - 1 : lo[a]; }
+    uint64_t cur = bx_entry(descriptors, root_index, descriptors[root_index]);
+    for (int top = 0;; top++) {
+        const int bb = n - top - 1;
+        const int i = ((v[0] >> bb) & 1) | (((v[1] >> bb) & 1) << 1) | (((v[2] >> bb) & 1) << 2);
+        const unsigned masks = (unsigned)cur & 0xffffu, bit = 1u << i;
+        if (!(masks & bit)) return;                       // empty: as promised
+        if (((masks >> 8) & bit) || bb == 0) { atomicAdd(&result[1], 1ULL); return; }
+        const uint64_t child = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
+        cur = bx_entry(descriptors, child, descriptors[child]);
+    }
+}
+
+}  // namespace
+
+// pos[n_desc]: position and level of every descriptor the root reaches (kPosNone for far-pointer slots, page headers, unused slots)
+hipError_t launch_box_positions(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, uint64_t *pos, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n < 1 || n > kPosBits || !n_desc || root_index >= n_desc) return hipErrorInvalidValue;
+    const unsigned tb = 256;
+    hipLaunchKernelGGL(box_fill_kernel, dim3((unsigned)((n_desc + tb - 1) / tb)), dim3(tb), 0, stream, pos, n_desc, kPosNone);
+    hipError_t e = hipMemsetAsync(pos + root_index, 0, sizeof(uint64_t), stream);     // the root: position (0, 0, 0), level 0
+    if (e != hipSuccess) return e;
+    for (int level = 0; level < n - 1; level++)
+        hipLaunchKernelGGL(box_positions_kernel, dim3((unsigned)((n_desc + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, n_desc, n, level, pos);
+    return hipGetLastError();
+}
+
+// Builds boxes[8 * n_desc] (and aux[2^(3 lc)] when lc >= 1) on `stream`.  `pos_tmp` = n_desc uint64 of scratch.  n <= 19.
+hipError_t launch_box_build(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, int lc, uint64_t *pos_tmp,
+                            uint32_t *boxes, uint32_t *aux, hipStream_t stream) {
+    hipError_t e = launch_box_positions(descriptors, n_desc, root_index, n, pos_tmp, stream);
+    if (e != hipSuccess) return e;
+    const unsigned tb = 256;
+    const uint64_t threads = n_desc * 8;
+    hipLaunchKernelGGL(box_grow_kernel, dim3((unsigned)((threads + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, n_desc, root_index, n, pos_tmp, boxes);
+    if (aux && lc >= 1) {
+        const uint64_t cells = 1ULL << (3 * lc);
+        hipLaunchKernelGGL(box_aux_kernel, dim3((unsigned)((cells + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, root_index, n, lc, boxes, aux);
+    }
+    return hipGetLastError();
+}
+
+// result[0] = boxes sampled, result[1] = sampled voxels the tree calls solid (must be 0); `result` is device memory, zeroed here
+hipError_t launch_box_check(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, const uint64_t *pos,
+                            const uint32_t *boxes, uint64_t samples, uint64_t seed, unsigned long long *result, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipError_t e = hipMemsetAsync(result, 0, 2 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    if (!samples) return hipSuccess;
+    const unsigned tb = 256;
+    hipLaunchKernelGGL(box_check_kernel, dim3((unsigned)((samples + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, n_desc, root_index, n, pos, boxes, samples, seed, result);
+    return hipGetLastError();
+}
+
+}  // namespace vrc

@@ -164,9 +164,17 @@ constexpr int kHwRegXccId = (3 << 11) | (0 << 6) | 20;
 //         canonical one of SURVEY 8d (the descents the table stands for are counted by their number: level found - level of
 //         the common ancestor), so counters and hit records are those of the plain traversal, bit for bit.  The LDS stack
 //         then only holds the levels from lc down (slot = level - lc).
-template <bool kJump, bool kMulti, bool kTuned, bool kLdsTab = false, bool kCoarse = false>
+// kBox: an empty node is widened to the empty BOX the tree's builder-side pass found around it (empty_boxes.hip: RaycastParams::boxes
+//         per (descriptor, empty child), box_aux per table cell) instead of over its empty siblings: a ray that leaves or approaches
+//         a surface no longer pays a node event per octree level.  The step loop, its float sequence and the iteration count are
+//         what they were -- inside an empty box the loop reads no occupancy -- so frames and hit records stay bit-identical; only
+//         the descriptor-read counter now counts the reads this traversal makes, not SURVEY 8d's canonical ones (setting
+//         empty_boxes = 0 renders with the canonical counter).  The cursor keeps the INDEX of the descriptor whose masks it holds
+//         in a second LDS array beside the stack ([level - lc][thread], one dword).
+template <bool kJump, bool kMulti, bool kTuned, bool kLdsTab = false, bool kCoarse = false, bool kBox = false>
 __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
     static_assert(kJump || !kLdsTab, "tables exist for the jump instances only");
+    static_assert(kCoarse || !kBox, "the boxes hang on the coarse table's cells");
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1  (kCoarse: [level-lc][thread], levels lc..n-1)
     __shared__ unsigned long long block_ctr[kCtrCount];
     __shared__ int s_jump_slot;
@@ -229,22 +237,34 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     // returns b >= 0: voxel lies in an empty node of size 2^b;  -1: voxel is solid
     const int lc = kCoarse ? p.coarse_log2 : 0, csh = n - lc;           // table level, log2 of its cell size
     const int sbase = kCoarse ? lc : 1;                   // level of stack slot 0
+    // kBox: the descriptor index of every stack level, behind the stack; boxw = the box word of the empty node locate() found
+    uint32_t *const lds_own = reinterpret_cast<uint32_t *>(lds_stack + (size_t)(kCoarse ? n - lc : (n > 1 ? n - 1 : 1)) * kBlockThreads);
+    uint32_t boxw = 0;
     auto locate = [&](int x, int y, int z) -> int {
         const unsigned diff = (unsigned)((x ^ pvx) | (y ^ pvy) | (z ^ pvz));
+        uint32_t own = 0;                                 // kBox: index of the descriptor `cur` was made from (top >= lc), or the cell's box word (top < lc)
         if (kCoarse && (top < lc || (diff >> csh) != 0)) {
             // the cursor of the new cell comes from the table; the canonical traversal would have popped to level a (the deepest
             // node that holds both voxels, or where the cursor already sits) and made t - a descents from there
             int a = n - (32 - __clz((int)diff));          // (diff == 0: n)
             a = a < top ? a : top;
             // (the cell index in 32 bits: the table's level is at most 10 -- vrc_api.cpp -- so it has at most 30)
-            const uint64_t e = p.coarse[(unsigned)(x >> csh) | ((unsigned)(y >> csh) << lc) | ((unsigned)(z >> csh) << (2 * lc))];
+            const unsigned cell = (unsigned)(x >> csh) | ((unsigned)(y >> csh) << lc) | ((unsigned)(z >> csh) << (2 * lc));
+            const uint64_t e = p.coarse[cell];
+            if (kBox) own = p.box_aux[cell];
             cur = e & ((1ULL << kCoarseLevelShift) - 1ULL);
             top = (int)(e >> kCoarseLevelShift);
             c_desc += (unsigned)(top - a);
-            if (top == lc) lds_stack[tid] = cur;          // slot 0 = level lc: pops inside the cell end here
-        } else if (top > 0 && (diff >> (n - top)) != 0) {
-            top = n - (31 - __clz((int)diff)) - 1;        // deepest level whose node holds both voxels
-            cur = (!kCoarse && top == 0) ? root_entry : lds_stack[(top - sbase) * kBlockThreads + tid];
+            if (top == lc) {                              // slot 0 = level lc: pops inside the cell end here
+                lds_stack[tid] = cur;
+                if (kBox) lds_own[tid] = own;
+            }
+        } else {
+            if (top > 0 && (diff >> (n - top)) != 0) {
+                top = n - (31 - __clz((int)diff)) - 1;    // deepest level whose node holds both voxels
+                cur = (!kCoarse && top == 0) ? root_entry : lds_stack[(top - sbase) * kBlockThreads + tid];
+            }
+            if (kBox) own = lds_own[(top - sbase) * kBlockThreads + tid];   // (top >= lc here: a cursor above the table's level always takes the table)
         }
         pvx = x; pvy = y; pvz = z;
         for (;;) {
@@ -252,13 +272,17 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             const int i = ((x >> b) & 1) | (((y >> b) & 1) << 1) | (((z >> b) & 1) << 2);
             const unsigned masks = (unsigned)cur & 0xffffu;
             const unsigned bit = 1u << i;
-            if (!(masks & bit)) return b;
+            if (!(masks & bit)) {
+                if (kBox) boxw = top < lc ? own : p.boxes[(size_t)own * 8u + (unsigned)i];
+                return b;
+            }
             if (((masks >> 8) & bit) || b == 0) return -1;
             const uint64_t child = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
             const uint64_t d = descriptors[child];
             c_desc++;
             cur = make_entry(descriptors, child, d);
             lds_stack[(top + 1 - sbase) * kBlockThreads + tid] = cur;   // level top+1 (>= lc + 1 with the table)
+            if (kBox) { own = (uint32_t)child; lds_own[(top + 1 - sbase) * kBlockThreads + tid] = own; }
             top++;
         }
     };
@@ -283,6 +307,21 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     // the mask calls empty would have been found empty without any descriptor read).
     auto enter_node = [&](int b) {
         const int size = 1 << b;
+        if (kBox) {
+            // the node at (v & ~(size - 1)) extended by the box word's extents on the three sides the ray can leave through, clamped
+            // to the map (beyond it everything is empty, but the :563 bounds test must see the crossing)
+            auto side = [&](int s, int v, int axis, int dim, int &base, float &count) {
+                const unsigned c = (boxw >> (unsigned)(5 * axis + (s > 0 ? 15 : 0))) & 31u;
+                const int ext = (c < 4u ? (int)c : (int)((4u | (c & 3u)) << ((c >> 2) - 1u))) << b;
+                const int o = v & ~(size - 1);
+                if (s > 0) { const int f = o + size + ext; base = f < dim ? f : dim; count = (float)(base - v); }
+                else { const int f = o - ext; base = (f > 0 ? f : 0) - 1; count = (float)(v - base); }
+            };
+            side(r.sx, r.vx, 0, p.map_dim[0], bx, nx);
+            side(r.sy, r.vy, 1, p.map_dim[1], by, ny);
+            side(r.sz, r.vz, 2, p.map_dim[2], bz, nz);
+            return;
+        }
         const unsigned valid = (unsigned)cur & 0xffu;
         const int i = ((r.vx >> b) & 1) | (((r.vy >> b) & 1) << 1) | (((r.vz >> b) & 1) << 2);
         // axis a can be widened when the ray moves from this half of the parent toward the other half: child bit a differs
@@ -324,7 +363,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
     // rows in LDS: behind the traversal stack, [ring row][pair][thread], one dword each (consecutive threads, consecutive banks)
     constexpr int kRing = kLdsTab ? VRC_LDS_RING : 4;    // table rows per ray (exact_jump.hpp)
     const int jstride = kLdsTab ? kBlockThreads : 64;
-    if (kLdsTab) jtab = reinterpret_cast<uint32_t *>(lds_stack + (size_t)(kCoarse ? n - lc : (n > 1 ? n - 1 : 1)) * kBlockThreads) + tid;
+    if (kLdsTab) jtab = lds_own + (kBox ? (size_t)(n - lc) * kBlockThreads : 0) + tid;
     else if (kJump && s_jump_slot >= 0) jtab = p.jump_cache + ((size_t)s_jump_slot * kTilesPerBlock + (tid >> 6)) * (size_t)(3 * kRing * 64) + (tid & 63);
 
     if (in_image) {
@@ -910,9 +949,11 @@ hipError_t launch_raycast_jump(const RaycastParams &p, hipStream_t stream);   //
 static bool svo_uses_coarse(const RaycastParams &p) {
     return p.coarse != nullptr && p.coarse_log2 >= 1 && p.coarse_log2 <= p.log2_dim - 2;
 }
+static bool svo_uses_boxes(const RaycastParams &p) { return svo_uses_coarse(p) && p.boxes != nullptr && p.box_aux != nullptr; }
 static size_t svo_stack_bytes(const RaycastParams &p) {
     const int levels = svo_uses_coarse(p) ? p.log2_dim - p.coarse_log2 : (p.log2_dim > 1 ? p.log2_dim - 1 : 1);
-    return (size_t)levels * kBlockThreads * sizeof(uint64_t) + (size_t)p.lds_pad_bytes;
+    // (with the boxes: a dword per level and thread for the descriptor index, behind the 8-byte entries)
+    return (size_t)levels * kBlockThreads * (sizeof(uint64_t) + (svo_uses_boxes(p) ? sizeof(uint32_t) : 0)) + (size_t)p.lds_pad_bytes;
 }
 constexpr size_t kLdsTabBytes = (size_t)(3 * VRC_LDS_RING) * kBlockThreads * sizeof(uint32_t);   // ring rows x 3 pairs, one dword per thread
 
@@ -926,17 +967,29 @@ bool jump_tables_in_lds(const RaycastParams &p) {
     const size_t lds = svo_stack_bytes(p) + kLdsTabBytes;
     static std::mutex guard;                             // (handles of several host threads may ask at the same time)
     std::lock_guard<std::mutex> lock(guard);
-    static size_t cached_lds = ~(size_t)0;
-    static bool cached = false;
-    if (cached_lds != lds) {
+    // asked of the instance that will run (single- / multi-light, with / without the table and the boxes) on the current device,
+    // once per (device, instance, LDS size)
+    const bool coarse = svo_uses_coarse(p), box = svo_uses_boxes(p), multi = p.light_count > 1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long key = ((unsigned long long)lds << 16) | ((unsigned long long)(dev & 0xff) << 8) | (coarse ? 1u : 0u) | (box ? 2u : 0u) | (multi ? 4u : 0u);
+    static unsigned long long cached_key[8] = {~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL};
+    static bool cached[8];
+    const int slot = (coarse ? 1 : 0) | (box ? 2 : 0) | (multi ? 4 : 0);
+    if (cached_key[slot] != key) {
+        const void *fn = box ? (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, true, true, true>)
+                                      : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, true, true>))
+                       : coarse ? (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, true, true>)
+                                         : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, true>))
+                                : (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, true, false>)
+                                         : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, false>));
         int per_cu = 0;
-        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, true>),
-                                                                          kBlockThreads, lds);
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlockThreads, lds);
         (void)hipGetLastError();
-        cached = e == hipSuccess && per_cu >= VRC_MIN_BLOCKS_JUMP;
-        cached_lds = lds;
+        cached[slot] = e == hipSuccess && per_cu >= VRC_MIN_BLOCKS_JUMP;
+        cached_key[slot] = key;
     }
-    return cached;
+    return cached[slot];
 }
 
 hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
@@ -954,9 +1007,13 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
                            p.exact_steps == kDefaultExactSteps && p.burst_steps == kDefaultBurstSteps;
         if (jump && !lds_tab && (!p.jump_cache || !p.jump_slots || p.jump_slot_count < 1)) return hipErrorInvalidValue;
 #define VRC_LAUNCH(...) hipLaunchKernelGGL((raycast_svo_kernel<__VA_ARGS__>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p)
-#define VRC_LAUNCH_MT(J, L, C) do { if (multi && tuned) VRC_LAUNCH(J, true, true, L, C); else if (multi) VRC_LAUNCH(J, true, false, L, C); \
-                                    else if (tuned) VRC_LAUNCH(J, false, true, L, C); else VRC_LAUNCH(J, false, false, L, C); } while (0)
-        if (svo_uses_coarse(p)) {
+#define VRC_LAUNCH_MT(J, L, ...) do { if (multi && tuned) VRC_LAUNCH(J, true, true, L, __VA_ARGS__); else if (multi) VRC_LAUNCH(J, true, false, L, __VA_ARGS__); \
+                                    else if (tuned) VRC_LAUNCH(J, false, true, L, __VA_ARGS__); else VRC_LAUNCH(J, false, false, L, __VA_ARGS__); } while (0)
+        if (svo_uses_boxes(p)) {
+            if (lds_tab) VRC_LAUNCH_MT(true, true, true, true);
+            else if (jump) VRC_LAUNCH_MT(true, false, true, true);
+            else VRC_LAUNCH_MT(false, false, true, true);
+        } else if (svo_uses_coarse(p)) {
             if (lds_tab) VRC_LAUNCH_MT(true, true, true);
             else if (jump) VRC_LAUNCH_MT(true, false, true);
             else VRC_LAUNCH_MT(false, false, true);

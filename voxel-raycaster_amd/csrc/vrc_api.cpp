@@ -27,6 +27,11 @@ namespace vrc {
 hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream);
 bool jump_tables_in_lds(const RaycastParams &p);
 hipError_t launch_coarse_build(const uint64_t *descriptors, uint64_t root_index, int log2_dim, int lc, uint64_t *out, hipStream_t stream);
+hipError_t launch_box_positions(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, uint64_t *pos, hipStream_t stream);
+hipError_t launch_box_build(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, int lc, uint64_t *pos_tmp,
+                            uint32_t *boxes, uint32_t *aux, hipStream_t stream);
+hipError_t launch_box_check(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, const uint64_t *pos,
+                            const uint32_t *boxes, uint64_t samples, uint64_t seed, unsigned long long *result, hipStream_t stream);
 hipError_t launch_frame_setup(const RaycastParams &p, hipStream_t stream);
 hipError_t launch_reduce_counters(const unsigned long long *partials, int nblocks, unsigned long long *out,
                                   hipStream_t stream);
@@ -56,6 +61,8 @@ struct vrc_caster {
     uint64_t *d_desc = nullptr; uint64_t n_desc = 0; bool have_octree = false;
     // mode B's coarse table of the tree (vrc_params.h RaycastParams::coarse), built on first use: valid for (root, depth, level)
     uint64_t *d_coarse = nullptr; uint64_t coarse_root = 0; int coarse_depth = 0, coarse_log2 = 0;
+    // the empty boxes of the tree (empty_boxes.hip), built with the coarse table: valid for (root, depth, table level)
+    uint32_t *d_boxes = nullptr, *d_box_aux = nullptr; uint64_t box_root = 0; int box_depth = 0, box_log2 = 0; double box_build_seconds = 0.0;
     bool owns_desc = true;                // false: a group rank on the same GPU as rank 0 shares rank 0's arrays
     bool own_copy = false;                // group flag VRC_GROUP_OWN_COPIES: never share, always take the device-to-device copy path
     int32_t peer_access = -1;             // -1 same GPU as rank 0 / rank 0 itself, 1 direct peer access enabled, 0 the runtime stages the copies
@@ -134,6 +141,7 @@ void release(T *&p) {
 
 void release_tree(vrc_caster *h) {
     release(h->d_coarse); h->coarse_log2 = 0;                      // the table describes the tree that goes away
+    release(h->d_boxes); release(h->d_box_aux); h->box_log2 = 0;
     if (h->owns_desc) { release(h->d_desc); release(h->d_attach_lookup); release(h->d_attach); }
     h->d_desc = nullptr; h->d_attach_lookup = nullptr; h->d_attach = nullptr;
     h->owns_desc = true;
@@ -1012,6 +1020,36 @@ int compute_async_one(vrc_caster *h) {
         } else {
             release(h->d_coarse); h->coarse_log2 = 0;             // the setting went to "none": the table goes too
         }
+        // the empty boxes (setting empty_boxes: -1 = when the tree is small enough for them, 0 = never, 1 = always): 32 bytes per
+        // descriptor + 4 per table cell, built here on first use like the table they hang on; exact mode only
+        const int64_t want_boxes = setting_or(h, "empty_boxes", -1);
+        const bool box_ok = p.coarse != nullptr && p.stepping_mode == 0 && p.log2_dim <= 19 && h->n_desc < (1ULL << 31);
+        if (box_ok && (want_boxes > 0 || (want_boxes < 0 && h->n_desc <= (1ULL << 28)))) {
+            if (!h->d_boxes || h->box_log2 != (int)lc || h->box_root != p.root_index || h->box_depth != p.log2_dim) {
+                release(h->d_boxes); release(h->d_box_aux);
+                h->box_log2 = 0;
+                uint64_t *pos_tmp = nullptr;
+                HIP_TRY(h, hipMalloc((void **)&h->d_boxes, sizeof(uint32_t) * 8 * h->n_desc));
+                HIP_TRY(h, hipMalloc((void **)&h->d_box_aux, sizeof(uint32_t) << (3 * lc)));
+                HIP_TRY(h, hipMalloc((void **)&pos_tmp, sizeof(uint64_t) * h->n_desc));
+                hipEvent_t e0, e1;
+                HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
+                HIP_TRY(h, hipEventRecord(e0, h->stream));
+                const hipError_t be = vrc::launch_box_build(h->d_desc, h->n_desc, p.root_index, p.log2_dim, (int)lc, pos_tmp, h->d_boxes, h->d_box_aux, h->stream);
+                HIP_TRY(h, hipEventRecord(e1, h->stream));
+                const hipError_t se = hipStreamSynchronize(h->stream);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+                (void)hipFree(pos_tmp);
+                HIP_TRY(h, be); HIP_TRY(h, se);
+                h->box_build_seconds = ms * 1e-3;
+                h->box_log2 = (int)lc; h->box_root = p.root_index; h->box_depth = p.log2_dim;
+            }
+            p.boxes = h->d_boxes; p.box_aux = h->d_box_aux;
+        } else if (h->d_boxes && want_boxes == 0) {
+            release(h->d_boxes); release(h->d_box_aux); h->box_log2 = 0;   // the setting went to "never": the boxes go too
+        }
     }
     // exact closed-form jumps: on from depth 12; the threshold depends on where the Euclid tables live (LDS when stack + tables
     // fit at full occupancy: depth 12)
@@ -1159,6 +1197,27 @@ int vrc_unpin_host_buffer(void *p) {
     if (hipHostUnregister(p) == hipSuccess) return VRC_OK;
     (void)hipGetLastError();                 // reported through the return code, not left behind for the next launch
     return VRC_ERR_DEVICE;
+}
+
+// self-check of the empty boxes the last frame used: pseudo-random voxels inside pseudo-random boxes, looked up in the tree
+int vrc_empty_boxes_check(vrc_caster *h, uint64_t samples, uint64_t seed, uint64_t *boxes_sampled, uint64_t *solid_voxels, double *build_seconds) {
+    if (!h) return VRC_ERR_INVALID_ARGUMENT;
+    if (!h->d_boxes || !h->d_desc) return fail(h, VRC_ERR_NOT_READY, "empty_boxes_check: no boxes (setting empty_boxes, or no frame computed yet)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    uint64_t *pos = nullptr; unsigned long long *res = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&pos, sizeof(uint64_t) * h->n_desc));
+    hipError_t e = hipMalloc((void **)&res, 2 * sizeof(unsigned long long));
+    unsigned long long out[2] = {0, 0};
+    if (e == hipSuccess) e = vrc::launch_box_positions(h->d_desc, h->n_desc, h->box_root, h->box_depth, pos, h->stream);
+    if (e == hipSuccess) e = vrc::launch_box_check(h->d_desc, h->n_desc, h->box_root, h->box_depth, pos, h->d_boxes, samples, seed, res, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, res, sizeof(out), hipMemcpyDeviceToHost);
+    (void)hipFree(pos); (void)hipFree(res);
+    HIP_TRY(h, e);
+    if (boxes_sampled) *boxes_sampled = out[0];
+    if (solid_voxels) *solid_voxels = out[1];
+    if (build_seconds) *build_seconds = h->box_build_seconds;
+    return VRC_OK;
 }
 
 int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out) {

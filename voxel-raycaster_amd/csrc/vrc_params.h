@@ -135,6 +135,11 @@ struct RaycastParams {
     // bits 0-15 leaf << 8 | valid, 16-58 absolute index of the first kept child, 59-63 the level of that node.  nullptr: no table
     const uint64_t *coarse;
     int32_t coarse_log2;
+    // empty boxes (empty_boxes.hip; needs the coarse table): boxes[8 * descriptor + child slot] = six 5-bit extents by which an
+    // empty child node may be widened, box_aux[cell] = the table's parallel word (the box of the empty node a cell resolves to
+    // above the table's level, or the index of the level-coarse_log2 descriptor).  nullptr: nodes + sibling widening only
+    const uint32_t *boxes;
+    const uint32_t *box_aux;
     unsigned long long *counters;
     // host-mapped flag the round watchdog raises (checked by vrc_sync: a truncated frame never looks like success)
     unsigned int *watchdog_flag;
