@@ -130,8 +130,11 @@ def supersampled_table(width: int, height: int, n: int) -> np.ndarray:
     return t
 
 
-def _scene_tree(c, sc, octree_file):
-    """The SVO into this caster's HBM: uploaded from the host array, streamed from rank 0's file, or built on the device."""
+def _scene_tree(c, sc, octree_file, tree_from=None):
+    """The SVO into this caster's HBM: uploaded from the host array, streamed from rank 0's file, built on the device -- or
+    adopted from a caster on the same GPU that already holds it (one array, one coarse table, one set of empty boxes)."""
+    if tree_from is not None:
+        return c.assign_octree_from(tree_from)
     if sc.get("device_built"):
         info, _ = c.build_shell_terrain(sc["depth"], 1, sc["thickness"], 2)
         sc["n_desc"] = int(info["n_descriptors"])
@@ -142,7 +145,7 @@ def _scene_tree(c, sc, octree_file):
 
 
 def make_caster(sc, width, height, device, table=None, shadow_rays=1, light_count=1, row_slice=None, octree_file=None,
-                hit_records=1):
+                hit_records=1, tree_from=None):
     import voxel_raycaster_amd as vrc
     c = vrc.CLCaster()
     if not c.init(device):
@@ -155,7 +158,7 @@ def make_caster(sc, width, height, device, table=None, shadow_rays=1, light_coun
           and c.add_to_settings_buffer("shadow_rays", "SHADOW_RAYS", shadow_rays)
           and c.add_to_settings_buffer("light_count", "LIGHT_COUNT", light_count)
           and c.add_to_settings_buffer("hit_records", "HIT_RECORDS", hit_records)
-          and _scene_tree(c, sc, octree_file)
+          and _scene_tree(c, sc, octree_file, tree_from)
           and c.assign_camera(sc["cam_dir"], sc["cam_pos"])
           and (c.create_viewport(width, height) if table is None else c.create_viewport_table(table))
           and c.assign_lights(sc["lights"])
@@ -188,6 +191,31 @@ def reduce_over_ranks(rays: int, seconds: float):
     dist.all_reduce(r, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(round(r.item())), float(t.item())
+
+
+def canonical_counters(c) -> dict:
+    """Counters of one frame rendered by the canonical traversal (empty_boxes = 0): SURVEY 8d's N_desc."""
+    if not (c.overwrite_setting("empty_boxes", 0) or c.add_to_settings_buffer("empty_boxes", "EMPTY_BOXES", 0)):
+        raise SystemExit("bench: " + c.last_error())
+    if not c.compute():
+        raise SystemExit("compute failed: " + c.last_error())
+    ctr = c.counters()
+    assert ctr["canonical_reads"]
+    assert c.overwrite_setting("empty_boxes", -1)
+    return ctr
+
+
+def kernel_instance(c, sc, lights) -> str:
+    """The template instance vrc_api.cpp / raycast_kernel.hip launch_raycast picks for this caster's default settings."""
+    m = c.memory_usage2()
+    jump = sc["depth"] >= 12
+    flags = [jump, lights > 1, True, jump, m["coarse_log2"] > 0, bool(m["empty_boxes"])]
+    return "raycast_svo_kernel<" + ", ".join("true" if f else "false" for f in flags) + ">  (kJump, kMulti, kTuned, kLdsTab, kCoarse, kBox)"
+
+
+def tree_state(c) -> dict:
+    m = c.memory_usage2()
+    return {k: m[k] for k in ("octree_bytes", "coarse_bytes", "coarse_log2", "box_bytes", "empty_boxes", "box_build_seconds", "tree_holders", "note")}
 
 
 def algorithmic_bytes(ctr: dict, pixels: int, written: int) -> int:
@@ -297,6 +325,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-survey-camera", action="store_true",
                     help="skip the survey_camera leg (the rocprofv3 --stats run: every launch of the kernel is then the headline frame)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other_configs leg (BASELINE configs[1], configs[3] geometry and the 4-light headline on this GPU)")
     ap.add_argument("--no-build", action="store_true",
                     help="never spawn a compiler: fail if a library is stale (required under rocprofv3: the profiler's preloaded "
                          "library must not be inherited by child processes of a GPU-initialised program)")
@@ -367,7 +397,11 @@ def main():
 
     # what a caller sees without any pre-warming: the first `steps` frames of this fresh process (clocks still ramping),
     # reported beside `value` as value_no_prewarm
-    assert c.compute(), c.last_error()                             # (first launch: code object load)
+    # SURVEY 8d's N_desc is the CANONICAL traversal's read count -- a property of the workload, not of the kernel.  The product
+    # frame is rendered with the tree's empty boxes (setting empty_boxes), which make fewer reads; one untimed
+    # frame without them gives the canonical count the algorithmic bytes are priced with.
+    canonical_ctr = canonical_counters(c)
+    assert c.compute(), c.last_error()                             # (first launch with the default settings: builds the boxes)
     ctr0 = c.counters()
     torch.cuda.synchronize()
     tc = time.perf_counter()
@@ -410,7 +444,7 @@ def main():
         from voxel_raycaster_amd import tiling
         local_pixels = W * len(tiling.rows_of_rank(full_h, rank, world, 8))
         written = local_pixels - ctr["unwritten_pixels"]
-        bytes_per_launch = algorithmic_bytes(ctr, local_pixels, written)
+        bytes_per_launch = algorithmic_bytes(canonical_ctr, local_pixels, written)
         avg_kernel_s = kernel_ms / max(n_launch, 1) / 1e3
         achieved = bytes_per_launch / avg_kernel_s / 1e9
         # HBM bytes and VALU instructions per launch come from rocprofv3 PMC passes (tools/gpu_profile.sh: counters cannot be
@@ -430,7 +464,7 @@ def main():
                     traffic_split = {"fetch_bytes": int(2 * pmc["fetch_size_kib_raw"] * 1024), "write_bytes": int(pmc["write_size_kib_raw"] * 1024),
                                      "frame_bytes": int(16 * written),
                                      "write_over_frame": round(pmc["write_size_kib_raw"] * 1024 / max(16 * written, 1), 2),
-                                     "algorithmic_descriptor_bytes": int(8 * ctr["descriptor_reads"])}
+                                     "algorithmic_descriptor_bytes": int(8 * canonical_ctr["descriptor_reads"])}
                 valu = pmc.get("valu_insts_per_launch")
                 if valu:
                     # the float recurrence of ray_caster_kernel.cl:558-559 (min, three masks, three fused updates = 10 wave64
@@ -471,7 +505,9 @@ def main():
                        "stepping": "exact per-voxel DDA, bit-identical to the oracle (oracle/vrc_oracle.c); oracle vs the reference's own gfx950 "
                                    "build of kernels/ray_caster_kernel.cl: integer decisions (hit voxel, face, material, step counts) equal, RGB within "
                                    "1e-5 relative on 99.99 % of shaded pixels (the OpenCL library's 1-2 ulp normalize, DESIGN.md 2).  Long empty runs in "
-                                   "closed form (exact_jump.hpp: same float sequence and iteration count), setting jump_min_run",
+                                   "closed form (exact_jump.hpp: same float sequence and iteration count), setting jump_min_run; empty nodes widened to "
+                                   "the empty boxes the tree's device-side pass found around them (empty_boxes.hip, setting empty_boxes): fewer node "
+                                   "events, the same steps",
                        "prewarm_frames": PREWARM_FRAMES,
                        "frame": "production frame: image only, like the reference (hit_records = 0); with_hit_records is the same frame plus the parity records",
                        "multi_gpu": ("no N > 1 hardware measurement is recorded in this repository (SCALE_r01..r03 were skipped: no 8-GPU node); "
@@ -484,11 +520,20 @@ def main():
                          "binding_roof": "valu_issue",
                          "note": "exact-parity traversal is bound by VALU issue and by the latency of its dependent chains (DESIGN.md 4), not by "
                                  "HBM: frac is kept on HBM as BASELINE defines it, valu_issue says what the kernel issues",
-                         "descriptor_reads": ctr["descriptor_reads"], "steps": ctr["steps"], "valu_issue": issue,
+                         "descriptor_reads": canonical_ctr["descriptor_reads"],
+                         "descriptor_reads_note": "SURVEY 8d's canonical count (one untimed frame with empty_boxes = 0); the timed frames use the "
+                                                  "tree's empty boxes and read " + str(ctr["descriptor_reads"]) + " descriptors + table cells",
+                         "steps": ctr["steps"], "valu_issue": issue, "kernel_instance": kernel_instance(c, sc, args.lights),
+                         "tree_state": tree_state(c),
                          "pmc_source": pmc_note, "kernel_source_hash": kernel_source_hash()},
         }
         if world == 1 and not sc.get("device_built") and not args.no_survey_camera:
             out["survey_camera"] = survey_camera_leg(sc, c, args)
+        if world == 1 and headline and not args.no_other_configs and not args.no_survey_camera:
+            try:
+                out["other_configs"] = other_configs(sc, c, local_rank, args)
+            except Exception as e:                 # a supplementary leg must never take the headline line down
+                out["other_configs"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and not sc.get("device_built"):
             out.update(supplementary(sc, c, W, H, local_rank, args, rays_per_step))
         if dist_on and world == 1:
@@ -527,6 +572,7 @@ def survey_camera_leg(sc, c, args):
     pos = np.ascontiguousarray(sc["survey_cam_pos"], dtype=np.float32)
     assert c.assign_camera(sc["cam_dir"], pos) and c.validate(), c.last_error()
     try:
+        canon = canonical_counters(c)
         for _ in range(5):
             assert c.compute(), c.last_error()
         ctr = c.counters()
@@ -546,8 +592,46 @@ def survey_camera_leg(sc, c, args):
         W, H = c.viewport_size
         assert c.assign_camera(sc["cam_dir"], sc["cam_pos"]) and c.create_viewport(W, H) and c.validate(), c.last_error()
     return {"ms_per_step": round(dt / args.steps * 1e3, 4), "value": round(rays * args.steps / dt / 1e6, 3), "unit": "Mrays/s",
-            "kernel_ms_avg": round(ms / max(nl, 1), 4), "rays_per_step": int(rays), "steps": ctr["steps"], "descriptor_reads": ctr["descriptor_reads"],
+            "kernel_ms_avg": round(ms / max(nl, 1), 4), "rays_per_step": int(rays), "steps": ctr["steps"], "descriptor_reads": canon["descriptor_reads"],
             "camera": {"position": [float(v) for v in pos], "octree_bias": 1, "note": "SURVEY 8d pose as written; the reference's bias term is non-zero here"}}
+
+
+def other_configs(sc, c, device, args):
+    """the BASELINE configs beside the headline, timed by the driver's own run on the one GPU every round --
+    configs[1] (depth 10, primary rays only), configs[3]'s geometry (4K, 2 lights: the multi-light instance) and the headline
+    scene with 4 lights.  Kernel time from HIP events over `steps` frames each; never part of `value`.  The depth-12 legs adopt
+    the headline caster's tree (one array, one table, one set of boxes on the GPU)."""
+    legs = []
+
+    def leg(name, scene, q, w, h, lights):
+        canon = canonical_counters(q)
+        for _ in range(3):
+            assert q.compute(), q.last_error()
+        ctr = q.counters()
+        q.timing_reset()
+        for _ in range(args.steps):
+            assert q.compute(), q.last_error()
+        nl, ms = q.timing()
+        k = ms / max(nl, 1) / 1e3
+        rays = ctr["primary_rays"] + ctr["shadow_rays"]
+        b = algorithmic_bytes(canon, w * h, w * h - canon["unwritten_pixels"])
+        legs.append({"config": name, "frame": f"{w}x{h}", "lights": lights, "kernel_ms_avg": round(k * 1e3, 4), "frames": int(nl),
+                     "Mrays_s": round(rays / k / 1e6, 1), "rays_per_frame": int(rays), "steps": ctr["steps"],
+                     "roofline": {"bound": "hbm", "achieved": round(b / k / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(b / k / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": int(b)},
+                     "kernel_instance": kernel_instance(q, scene, lights)})
+
+    sc10 = build_scene(10)
+    q = make_caster(sc10, 1920, 1080, device, shadow_rays=0, hit_records=0)
+    leg("BASELINE configs[1]: 1024^3 (depth-10) SVO, 1920x1080, primary rays only", sc10, q, 1920, 1080, 1)
+    del q
+    q = make_caster(sc, 3840, 2160, device, light_count=2, hit_records=0, tree_from=c)
+    leg("BASELINE configs[3] geometry on ONE GPU: 4096^3 (depth-12) SVO, 3840x2160, primary + shadow rays toward 2 lights", sc, q, 3840, 2160, 2)
+    del q
+    q = make_caster(sc, 1920, 1080, device, light_count=4, hit_records=0, tree_from=c)
+    leg("headline scene with 4 lights (configs[4]'s light count): 4096^3 (depth-12) SVO, 1920x1080", sc, q, 1920, 1080, 4)
+    del q
+    return legs
 
 
 def supplementary(sc, c, W, H, device, args, rays_per_step):
@@ -567,7 +651,7 @@ def supplementary(sc, c, W, H, device, args, rays_per_step):
     # two frames in flight (a second caster = second HIP stream + its own buffers) hide the kernel's ramp-up and tail;
     # the headline `value` is one frame at a time, like CLCaster::compute
     assert c.overwrite_setting("hit_records", 0)
-    c2 = make_caster(sc, W, H, device, hit_records=0, shadow_rays=args.shadow_rays, light_count=args.lights)
+    c2 = make_caster(sc, W, H, device, hit_records=0, shadow_rays=args.shadow_rays, light_count=args.lights, tree_from=c)
     for _ in range(2):
         assert c2.compute(), c2.last_error()
     torch.cuda.synchronize()
@@ -578,7 +662,9 @@ def supplementary(sc, c, W, H, device, args, rays_per_step):
         assert c.sync() and c2.sync()
     dtp = time.perf_counter() - tp
     out["two_frames_in_flight"] = {"value": round(rays_per_step * 2 * pairs / dtp / 1e6, 3), "unit": "Mrays/s",
-                                   "ms_per_frame": round(dtp / (2 * pairs) * 1e3, 4)}
+                                   "ms_per_frame": round(dtp / (2 * pairs) * 1e3, 4),
+                                   "tree_holders": c2.memory_usage2()["tree_holders"],
+                                   "note": "the second caster adopts the first one's tree (vrc_assign_octree_from): one array, one table, one set of boxes"}
     del c2
     assert c.overwrite_setting("hit_records", 1) and c.compute(), c.last_error()     # mode_b_report compares hit records
     gpu_frame = c.read_image()

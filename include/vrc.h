@@ -85,6 +85,12 @@ int vrc_assign_octree(vrc_caster *h, const uint64_t *descriptors, uint64_t n_des
  * ray_caster_kernel.cl:575); without them every valid voxel is material 5.        */
 int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_t n_lookup,
                                   const uint64_t *attachments, uint64_t n_attachments);
+/* CLCaster::assign_octree for a tree ANOTHER handle on the same GPU already holds (CLCaster.cpp:102-116 uploads the same
+ * array again for every caster and never frees it, :5-12): h adopts src's descriptor array, its materials and everything
+ * the kernels derive from them (the dense table of the tree's top, the empty boxes) -- they exist once, and live until the
+ * last handle that holds them releases them or is destroyed.  Materials assigned later through either handle are seen by
+ * both from their next frame on.                                                                                          */
+int vrc_assign_octree_from(vrc_caster *h, vrc_caster *src);
 /* CLCaster::release_octree (CLCaster.cpp:119-131) */
 int vrc_release_octree(vrc_caster *h);
 
@@ -204,6 +210,24 @@ typedef struct vrc_memory {
     uint64_t coarse_bytes;            /* the dense table of the tree's top (setting coarse_log2), 0 before the first frame */
 } vrc_memory;
 int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out);
+/* The same with a size-versioned struct: set struct_size = sizeof(vrc_memory2) before the call; the library writes no more
+ * than that many bytes and stores how many it wrote, so a host compiled against an older header keeps working when fields
+ * are appended.  (vrc_memory grew by coarse_bytes in round 4 without such a field: hosts compiled against the round-3 header
+ * must be recompiled or move to this call.)                                                                              */
+typedef struct vrc_memory2 {
+    uint32_t struct_size;             /* in: sizeof the caller's struct; out: bytes written */
+    int32_t  device, rows;
+    int32_t  octree_shared;           /* 1: the tree is also held by another handle (group rank on the same GPU, vrc_assign_octree_from) */
+    int32_t  peer_access;
+    int32_t  tree_holders;            /* handles that hold this rank's tree: its arrays, its coarse table and its boxes exist ONCE */
+    int32_t  coarse_log2;             /* level of the dense table of the tree's top, 0: none */
+    int32_t  empty_boxes;             /* 1: this rank's last frame was rendered with the tree's empty boxes (setting empty_boxes) */
+    uint64_t viewport_bytes, image_bytes, hit_bytes, octree_bytes;
+    uint64_t coarse_bytes, box_bytes; /* per TREE, not per handle */
+    double   box_build_seconds;
+    char     note[160];               /* why an optional structure is missing (allocation failure), else empty */
+} vrc_memory2;
+int vrc_memory_usage2(vrc_caster *h, int32_t rank, vrc_memory2 *out);
 
 /* Self-check of the empty boxes the last frame was rendered with (setting empty_boxes; a derived structure like the coarse
  * table, no counterpart in the reference: Octree.cpp never annotates empty space): `samples` pseudo-random (descriptor,

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402
 import voxel_raycaster_amd as vrc  # noqa: E402
 from oracle import orc  # noqa: E402
-from test_parity_gpu import make_caster  # noqa: E402
+from test_parity_gpu import hits_match, make_caster  # noqa: E402
 
 
 def run(budget=300.0, seed=1, depth=12, sc=None):
@@ -59,7 +59,7 @@ def run(budget=300.0, seed=1, depth=12, sc=None):
                                          tile_dim=(16, 16), descriptors=sc["octree"].descriptor_buffer,
                                          root_index=sc["octree"].root_index, octree_dim=dim, using_octree=0, max_distance=md,
                                          rows=(int(y0), int(y0) + 8), threads=16, active_lights=nl, stepping_mode=mode)
-            same = np.array_equal(hits[y0:y0 + 8], ohits[y0:y0 + 8]) and \
+            same = hits_match(c, hits[y0:y0 + 8], ohits[y0:y0 + 8]) and \
                 np.array_equal(img[y0:y0 + 8].view(np.uint32), oimg[y0:y0 + 8].view(np.uint32))
             rows += 8
             if not same:

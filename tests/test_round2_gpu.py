@@ -12,6 +12,7 @@ import pytest
 import scenes
 import voxel_raycaster_amd as vrc
 from oracle import orc
+from test_parity_gpu import hits_match
 
 pytestmark = pytest.mark.gpu
 
@@ -117,10 +118,10 @@ def test_device_built_scene_renders_like_the_oracle(atlas):
     oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas, tile_dim=(16, 16),
                                     descriptors=host.descriptor_buffer, root_index=host.root_index, octree_dim=dim,
                                     using_octree=0, max_distance=3 * dim, active_lights=2, threads=8)
-    assert np.array_equal(c.read_hits(), ohits)
+    assert hits_match(c, c.read_hits(), ohits)
     assert np.array_equal(c.read_image().view(np.uint32), oimg.view(np.uint32))
     ctr = c.counters()
-    assert ctr["descriptor_reads"] == octr["n_desc"] and ctr["steps"] == octr["n_steps"]
+    assert (ctr["descriptor_reads"] == octr["n_desc"] or not ctr["canonical_reads"]) and ctr["steps"] == octr["n_steps"]
 
 
 def test_configs4_scene_200GB_resident_sampled_rows(atlas):
@@ -187,7 +188,7 @@ def test_configs4_scene_200GB_resident_sampled_rows(atlas):
         oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas, tile_dim=(16, 16),
                                      descriptors=paged, root_index=root, octree_dim=dim, using_octree=0, max_distance=3 * dim,
                                      rows=(y0, y0 + 1), threads=threads, active_lights=4)
-        assert np.array_equal(hits[y0], ohits[y0]), f"row {y0}: {int((hits[y0] != ohits[y0]).any(-1).sum())} pixels differ"
+        assert hits_match(c, hits[y0], ohits[y0]), f"row {y0}: {int((hits[y0][..., :7] != ohits[y0][..., :7]).any(-1).sum())} pixels differ"
         assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
     print(f"oracle: {len(rows)} rows in {time.perf_counter() - t0:.1f} s on {threads} threads, {paged.bytes_fetched / 1e6:.0f} MB of descriptors fetched")
 
@@ -212,7 +213,7 @@ def test_headline_size_frame_with_the_reference_bias_active(atlas):
         oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas, tile_dim=(16, 16),
                                      descriptors=sc["octree"].descriptor_buffer, root_index=sc["octree"].root_index, octree_dim=dim,
                                      using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=16)
-        assert np.array_equal(hits[y0], ohits[y0])
+        assert hits_match(c, hits[y0], ohits[y0])
         assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
     # and it is not the frame the unbiased kernel renders
     assert c.add_to_settings_buffer("octree_bias", "OCTREE_BIAS", 0) and c.compute()
@@ -307,7 +308,7 @@ def test_configs3_eight_rank_group_sampled_rows():
         oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=g._li, atlas=sc["atlas"],
                                      tile_dim=(16, 16), descriptors=sc["octree"].descriptor_buffer, root_index=sc["octree"].root_index,
                                      octree_dim=dim, using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=16, active_lights=2)
-        assert np.array_equal(hits[y0], ohits[y0])
+        assert hits_match(g, hits[y0], ohits[y0])
         assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
 
 
@@ -359,7 +360,7 @@ def test_streamed_upload_multi_chunk_against_the_oracle(depth, chunk, tmp_path):
                                      tile_dim=(16, 16), descriptors=tree.descriptor_buffer, root_index=tree.root_index, octree_dim=dim,
                                      using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=16,
                                      attachment_lookup=tree.attachment_lookup, attachments=tree.attachment_buffer)
-        assert np.array_equal(hits[y0], ohits[y0])
+        assert hits_match(c, hits[y0], ohits[y0])
         assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
 
 
@@ -386,7 +387,7 @@ def test_a_new_tree_never_inherits_the_old_trees_materials(atlas):
     oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=t["cam_dir"], cam_pos=t["cam_pos"], lights=li, atlas=atlas, tile_dim=(16, 16),
                                  descriptors=bigger.descriptor_buffer, root_index=bigger.root_index, octree_dim=tdim, using_octree=0,
                                  max_distance=3 * tdim)
-    assert np.array_equal(c.read_hits(), ohits) and np.array_equal(c.read_image().view(np.uint32), oimg.view(np.uint32))
+    assert hits_match(c, c.read_hits(), ohits) and np.array_equal(c.read_image().view(np.uint32), oimg.view(np.uint32))
     bad = with_mat.attachment_lookup.copy()
     bad[5] = with_mat.attachment_buffer.size + 3
     import ctypes as C
@@ -499,7 +500,7 @@ def test_tiny_and_ragged_viewports(res, path, atlas):
     configure(g, dim, atlas, s["cam_dir"], s["cam_pos"], li, w, h)
     assert g.overwrite_setting("using_octree", using_octree) and g.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", mode)
     assert g.validate() and g.compute(), g.last_error()
-    assert np.array_equal(g.read_hits(), ohits) and np.array_equal(g.read_image().view(np.uint32), oimg.view(np.uint32))
+    assert hits_match(g, g.read_hits(), ohits) and np.array_equal(g.read_image().view(np.uint32), oimg.view(np.uint32))
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["exact", "mode_b"])

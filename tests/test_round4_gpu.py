@@ -105,7 +105,9 @@ def test_coarse_table_and_lds_tables_never_change_the_frame(depth, lights):
     sc = bench.build_scene(depth)
     w, h = (640, 360) if depth < 12 else (1920, 1080)
     c = bench.make_caster(sc, w, h, 0, light_count=lights)
-    for name, v in (("coarse_log2", 0), ("jump_tables_lds", 0), ("jump_min_run", 1 << 24)):
+    # (empty_boxes = 0: this test is about the CANONICAL read count, which the table path keeps; the boxes -- round 5, on by
+    # default wherever the table is -- count their own reads: tests/test_round5_gpu.py)
+    for name, v in (("coarse_log2", 0), ("jump_tables_lds", 0), ("jump_min_run", 1 << 24), ("empty_boxes", 0)):
         assert c.add_to_settings_buffer(name, name.upper(), v)
     ref = _frame(c)                                        # no table, no jumps: the plain traversal
     assert c.memory_usage()["coarse_bytes"] == 0

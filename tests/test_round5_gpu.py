@@ -1,0 +1,167 @@
+"""Round 5 (-m gpu): the empty boxes of the exact kernel (csrc/empty_boxes.hip) and the per-tree state handles share.
+
+The boxes are a derived structure like the coarse table: occupancy still comes from the descriptor array alone
+(Octree.h:89-94); inside a box the step loop of ray_caster_kernel.cl:555-570 reads no occupancy, so the float recurrence
+(:559), the iteration count (:714) and with them every pixel and every hit record are what they were.  Only the
+descriptor-read COUNT is the box traversal's own (field 7 of the hit records, counter descriptor_reads)."""
+import numpy as np
+import pytest
+
+import scenes
+import voxel_raycaster_amd as vrc
+from oracle import orc
+from test_parity_gpu import assert_same, hits_match, make_caster
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(c):
+    assert c.compute(), c.last_error()
+    return c.read_image().view(np.uint32).copy(), c.read_hits().copy(), c.counters()
+
+
+def _but_reads(ctr):
+    return {k: v for k, v in ctr.items() if k not in ("descriptor_reads", "canonical_reads")}
+
+
+@pytest.mark.parametrize("depth,lights,w,h", [(8, 1, 640, 360), (10, 2, 640, 360), (11, 1, 960, 540), (12, 1, 1920, 1080), (12, 4, 960, 540)],
+                         ids=["d8", "d10-2lights", "d11", "d12-headline", "d12-4lights"])
+def test_empty_boxes_never_change_the_frame(depth, lights, w, h):
+    """Boxes on / off, closed-form jumps on / off / forced from 2 iterations, Euclid tables in LDS or global: one image, one set
+    of hit records (the read count aside), the same counters; the boxes' self-check finds no solid voxel inside a box."""
+    import bench
+    sc = bench.build_scene(depth)
+    c = bench.make_caster(sc, w, h, 0, light_count=lights)
+    assert c.add_to_settings_buffer("empty_boxes", "EMPTY_BOXES", 0) and c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 1 << 24)
+    assert c.add_to_settings_buffer("jump_tables_lds", "JUMP_TABLES_LDS", 2)
+    ref = _frame(c)
+    assert not c.used_empty_boxes() and ref[2]["canonical_reads"]
+    for boxes in (1, -1):
+        for jmr, lds in ((1 << 24, 2), (16, 2), (2, 0)):
+            assert c.overwrite_setting("empty_boxes", boxes) and c.overwrite_setting("jump_min_run", jmr) and c.overwrite_setting("jump_tables_lds", lds)
+            img, hits, ctr = _frame(c)
+            tag = f"empty_boxes={boxes} jump_min_run={jmr} jump_tables_lds={lds}"
+            assert c.used_empty_boxes() and not ctr["canonical_reads"], tag
+            assert np.array_equal(img, ref[0]), f"{tag}: {int((img != ref[0]).any(-1).sum())} pixels differ"
+            assert np.array_equal(hits[..., :7], ref[1][..., :7]), f"{tag}: {int((hits[..., :7] != ref[1][..., :7]).any(-1).sum())} hit records differ"
+            assert _but_reads(ctr) == _but_reads(ref[2]), tag
+            assert ctr["descriptor_reads"] == int(hits[..., 7].astype(np.int64).sum())
+    chk = c.empty_boxes_check(1 << 22, seed=depth)
+    assert chk["boxes_sampled"] > 100000 and chk["solid_voxels"] == 0
+    m = c.memory_usage2()
+    assert m["empty_boxes"] == 1 and m["box_bytes"] > 32 * sc["octree"].descriptor_buffer.size and m["note"] == ""
+    print(f"\ndepth {depth}: boxes built in {chk['build_seconds'] * 1e3:.0f} ms, {m['box_bytes'] / 1e6:.0f} MB; descriptor reads "
+          f"{ref[2]['descriptor_reads'] / 1e6:.2f} M canonical, {ctr['descriptor_reads'] / 1e6:.2f} M with the boxes")
+    # back to the canonical traversal on the same handle: the canonical count again
+    assert c.overwrite_setting("empty_boxes", 0)
+    img, hits, ctr = _frame(c)
+    assert np.array_equal(hits, ref[1]) and {k: v for k, v in ctr.items()} == ref[2]
+
+
+@pytest.mark.parametrize("make", [scenes.floor_pillars, scenes.random_sparse, scenes.mirror_wall, scenes.open_sky],
+                         ids=["floor_pillars", "random_sparse", "mirror_wall", "open_sky"])
+def test_empty_boxes_on_dense_grid_trees_with_materials(make, atlas):
+    """Trees of Octree::Generate's own layout (100000-entry buffer, Octree.cpp:13-43) with attachments -- mirrors and
+    pass-through materials, rays inside solid, rays restarted by the hit block -- rendered with the boxes against the oracle."""
+    from test_oracle_cpu import _with_pass_through
+    s = _with_pass_through(make())
+    dim, w, h = s["dim"], 160, 120
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000).attach_materials_from_grid(s["grid"])
+    c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, 3 * dim, empty_boxes=1)
+    assert c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 2)
+    assert c.compute(), c.last_error()
+    assert c.used_empty_boxes() == (dim >= 32)
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=c._li, atlas=atlas,
+                                    tile_dim=(16, 16), descriptors=o.descriptor_buffer, root_index=o.root_index, octree_dim=dim,
+                                    using_octree=0, max_distance=3 * dim, attachment_lookup=o.attachment_lookup,
+                                    attachments=o.attachment_buffer)
+    assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+    if c.used_empty_boxes():
+        assert c.empty_boxes_check(1 << 18)["solid_voxels"] == 0
+
+
+def test_empty_boxes_exhaustive_check_on_a_small_tree(atlas):
+    """Every voxel of every box of a 64^3 tree against the dense grid (the device self-check samples; this one enumerates):
+    the boxes are read back through the frame they render -- a ray from every empty voxel along every axis direction steps
+    exactly as far as the oracle's ray does -- and through the sampled self-check with more samples than the tree has boxes."""
+    s = scenes.random_sparse()
+    dim = s["dim"]
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+    c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, 64, 48, 3 * dim, empty_boxes=1)
+    assert c.compute(), c.last_error()
+    n_boxes = 8 * o.descriptor_buffer.size
+    chk = c.empty_boxes_check(64 * n_boxes, seed=3)               # ~64 samples per (descriptor, child) pair
+    assert chk["solid_voxels"] == 0 and chk["boxes_sampled"] > n_boxes
+    # cameras all over the map, looking along and across the axes: frames equal the oracle's
+    rng = np.random.default_rng(11)
+    empty = np.argwhere(np.asarray(s["grid"]).reshape(dim, dim, dim) == 0)      # [z, y, x]
+    for k in range(12):
+        z, y, x = empty[rng.integers(len(empty))]
+        cam_pos = np.array([x + 0.31, y + 0.47, z + 0.59], dtype=np.float32)
+        cam_dir = np.array([rng.uniform(0.3, 2.8), rng.uniform(0.0, 6.2)], dtype=np.float32)
+        cc = make_caster(o, dim, 0, cam_dir, cam_pos, s["lights"], atlas, 64, 48, 3 * dim, empty_boxes=1)
+        assert cc.compute(), cc.last_error()
+        oimg, ohits, octr = orc.raycast(width=64, height=48, cam_dir=cam_dir, cam_pos=cam_pos, lights=cc._li, atlas=atlas, tile_dim=(16, 16),
+                                        descriptors=o.descriptor_buffer, root_index=o.root_index, octree_dim=dim, using_octree=0,
+                                        max_distance=3 * dim)
+        assert_same(cc.read_image(), cc.read_hits(), cc.counters(), oimg, ohits, octr)
+
+
+def test_trees_are_shared_not_copied():
+    """the coarse table and the boxes are functions of the TREE.  A second caster that adopts the first one's
+    tree (vrc_assign_octree_from) and the ranks of a same-GPU group hold ONE descriptor array, ONE table, ONE set of boxes;
+    frames are those of a caster with its own upload; the arrays outlive the handle that uploaded them."""
+    import bench
+    sc = bench.build_scene(10)
+    w, h = 640, 360
+    a = bench.make_caster(sc, w, h, 0)
+    ref = _frame(a)
+    ma = a.memory_usage2()
+    assert ma["tree_holders"] == 1 and ma["coarse_bytes"] > 0 and ma["box_bytes"] > 0 and ma["octree_shared"] == 0
+    b = vrc.CLCaster()
+    assert b.init(0)
+    for name, v in (("octree_dimensions", sc["dim"]), ("using_octree", 0), ("max_distance", 3 * sc["dim"])):
+        assert b.add_to_settings_buffer(name, name.upper(), v)
+    assert b.assign_octree_from(a), b.last_error()
+    assert (b.assign_camera(sc["cam_dir"], sc["cam_pos"]) and b.create_viewport(w, h) and b.assign_lights(sc["lights"])
+            and b.create_texture_atlas(sc["atlas"], (16, 16)) and b.validate()), b.last_error()
+    got = _frame(b)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+    mb = b.memory_usage2()
+    assert mb["tree_holders"] == 2 and mb["octree_shared"] == 1 and mb["coarse_bytes"] == ma["coarse_bytes"] and mb["box_bytes"] == ma["box_bytes"]
+    assert mb["box_build_seconds"] == ma["box_build_seconds"]        # not built a second time
+    del a                                                           # the uploader goes away: the tree stays with its last holder
+    import gc
+    gc.collect()
+    got = _frame(b)
+    assert np.array_equal(got[0], ref[0]) and b.memory_usage2()["tree_holders"] == 1
+    # an 8-rank group on one GPU: one tree between the ranks
+    g = vrc.CLCaster()
+    assert g.init_group([0] * 8, band_rows=8) and g.assign_octree(sc["octree"])
+    for name, v in (("octree_dimensions", sc["dim"]), ("using_octree", 0), ("max_distance", 3 * sc["dim"])):
+        assert g.add_to_settings_buffer(name, name.upper(), v)
+    assert (g.assign_camera(sc["cam_dir"], sc["cam_pos"]) and g.create_viewport(w, h) and g.assign_lights(sc["lights"])
+            and g.create_texture_atlas(sc["atlas"], (16, 16)) and g.validate()), g.last_error()
+    got = _frame(g)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+    mem = [g.memory_usage2(r) for r in range(8)]
+    assert all(m["tree_holders"] == 8 for m in mem) and [m["octree_shared"] for m in mem] == [0] + [1] * 7
+    assert len({m["box_build_seconds"] for m in mem}) == 1
+
+
+def test_optional_structures_fail_soft(atlas):
+    """the table and the boxes are accelerations, not requirements.  A tree in a map too large for the default
+    table gets a coarser one; with the table switched off there are no boxes and the frame is the same."""
+    s = scenes.floor_pillars(32)
+    dim = s["dim"]
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+    c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, 96, 64, 3 * dim)
+    ref = _frame(c)
+    assert c.used_empty_boxes()
+    assert c.add_to_settings_buffer("coarse_log2", "COARSE_LOG2", 0)
+    got = _frame(c)
+    assert not c.used_empty_boxes() and c.memory_usage2()["coarse_bytes"] == 0
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1][..., :7], ref[1][..., :7])
+    assert c.overwrite_setting("coarse_log2", -1)
+    got = _frame(c)
+    assert c.used_empty_boxes() and np.array_equal(got[1], ref[1]) and got[2] == ref[2]

@@ -61,6 +61,18 @@ class Memory(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class Memory2(C.Structure):
+    _fields_ = ([("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in ("device", "rows", "octree_shared", "peer_access", "tree_holders",
+                                                                      "coarse_log2", "empty_boxes")]
+                + [(n, C.c_uint64) for n in ("viewport_bytes", "image_bytes", "hit_bytes", "octree_bytes", "coarse_bytes", "box_bytes")]
+                + [("box_build_seconds", C.c_double), ("note", C.c_char * 160)])
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["note"] = d["note"].decode(errors="replace")
+        return d
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "primary_rays", "shadow_rays", "descriptor_reads", "texel_reads", "map_reads", "steps",
@@ -133,6 +145,8 @@ SIGNATURES = {
     "vrc_unpin_host_buffer": (C.c_int, [C.c_void_p]),
     "vrc_memory_usage": (C.c_int, [_H, C.c_int32, C.POINTER(Memory)]),
     "vrc_empty_boxes_check": (C.c_int, [_H, C.c_uint64, C.c_uint64, _u64p, _u64p, C.POINTER(C.c_double)]),
+    "vrc_assign_octree_from": (C.c_int, [_H, _H]),
+    "vrc_memory_usage2": (C.c_int, [_H, C.c_int32, C.POINTER(Memory2)]),
     "vrc_scene_shell_terrain_ex": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(_u64p), _u64p, _u64p, _i32p]),
     "vrc_scene_shell_column": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _i32p, _i32p]),
     "vrc_build_shell_terrain": (C.c_int, [_H, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint32, C.c_uint64, _i32p, C.c_uint32,
@@ -429,6 +443,23 @@ class CLCaster:
             raise VrcError(self.last_error())
         return m.as_dict()
 
+    def memory_usage2(self, rank: int = 0) -> dict:
+        """vrc_memory_usage2: the size-versioned form, with what is held per TREE (coarse table, empty boxes, holders)."""
+        m = Memory2()
+        m.struct_size = C.sizeof(Memory2)
+        if not self._ok(lib.vrc_memory_usage2(self._h, rank, C.byref(m))):
+            raise VrcError(self.last_error())
+        return m.as_dict()
+
+    def used_empty_boxes(self) -> bool:
+        """True when the last frame was rendered with the tree's empty boxes: the descriptor-read counts (counter and hit-record
+        field 7) are then those of the box traversal, not SURVEY 8d's canonical ones (setting empty_boxes = 0 gives those)."""
+        return bool(self.memory_usage2()["empty_boxes"])
+
+    def assign_octree_from(self, src: "CLCaster") -> bool:
+        """vrc_assign_octree_from: adopt the tree (arrays, coarse table, empty boxes) another caster on the same GPU holds."""
+        return self._ok(lib.vrc_assign_octree_from(self._h, src._h))
+
     def empty_boxes_check(self, samples: int = 1 << 20, seed: int = 1) -> dict:
         """vrc_empty_boxes_check: sampled voxels of the empty boxes the last frame used, looked up in the tree."""
         n, bad, sec = C.c_uint64(), C.c_uint64(), C.c_double()
@@ -656,7 +687,10 @@ class CLCaster:
         c = Counters()
         if not self._ok(lib.vrc_get_counters(self._h, C.byref(c))):
             raise VrcError(self.last_error())
-        return c.as_dict()
+        d = c.as_dict()
+        # descriptor_reads (and field 7 of the hit records) is SURVEY 8d's canonical count unless the frame used the empty boxes
+        d["canonical_reads"] = not self.used_empty_boxes()
+        return d
 
     def scheduler_stats(self) -> dict:
         out = (C.c_uint64 * 8)()

@@ -17,6 +17,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -51,6 +53,32 @@ int build_grid_device(hipStream_t stream, uint32_t depth, const int8_t *host_gri
 
 struct vrc_setting { std::string name, define; int64_t value; };
 
+// One descriptor array resident on one GPU, with its materials and with what the kernels derive from it (the dense table of
+// the tree's top, the empty boxes).  Everything here is a function of the TREE, not of a caster: the handles that render the
+// same array on the same GPU -- the ranks of a group that sit on rank 0's GPU, a handle that adopted another handle's tree
+// (vrc_assign_octree_from) -- hold one Tree between them, so the 1 GB table and the boxes exist once.  The reference never
+// frees or shares anything (CLCaster.cpp:5-12); this is footprint hygiene for trees of BASELINE configs[4]'s size.
+struct vrc_tree {
+    int device = 0;
+    uint64_t *d_desc = nullptr; uint64_t n_desc = 0;
+    uint32_t *d_attach_lookup = nullptr; uint64_t *d_attach = nullptr; uint64_t n_attach = 0;
+    // derived, built on first use by whichever handle needs them first (guard: handles of several host threads)
+    std::mutex guard;
+    uint64_t *d_coarse = nullptr; uint64_t coarse_root = 0; int coarse_depth = 0, coarse_log2 = 0;
+    uint32_t *d_boxes = nullptr, *d_box_aux = nullptr; uint64_t box_root = 0; int box_depth = 0, box_log2 = 0; double box_build_seconds = 0.0;
+    bool coarse_gave_up = false, boxes_gave_up = false;   // an allocation failed: the frames go on without (not retried every frame)
+    std::string note;                                     // why
+    ~vrc_tree() {
+        (void)hipSetDevice(device);
+        if (d_coarse) (void)hipFree(d_coarse);
+        if (d_boxes) (void)hipFree(d_boxes);
+        if (d_box_aux) (void)hipFree(d_box_aux);
+        if (d_desc) (void)hipFree(d_desc);
+        if (d_attach_lookup) (void)hipFree(d_attach_lookup);
+        if (d_attach) (void)hipFree(d_attach);
+    }
+};
+
 struct vrc_caster {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -58,15 +86,14 @@ struct vrc_caster {
 
     // scene buffers (device)
     int8_t *d_map = nullptr; int32_t map_dim[3] = {0, 0, 0};
+    // the tree (shared, see vrc_tree); d_desc / n_desc / d_attach* mirror its fields for the code that reads them
+    std::shared_ptr<vrc_tree> tree;
     uint64_t *d_desc = nullptr; uint64_t n_desc = 0; bool have_octree = false;
-    // mode B's coarse table of the tree (vrc_params.h RaycastParams::coarse), built on first use: valid for (root, depth, level)
-    uint64_t *d_coarse = nullptr; uint64_t coarse_root = 0; int coarse_depth = 0, coarse_log2 = 0;
-    // the empty boxes of the tree (empty_boxes.hip), built with the coarse table: valid for (root, depth, table level)
-    uint32_t *d_boxes = nullptr, *d_box_aux = nullptr; uint64_t box_root = 0; int box_depth = 0, box_log2 = 0; double box_build_seconds = 0.0;
-    bool owns_desc = true;                // false: a group rank on the same GPU as rank 0 shares rank 0's arrays
+    bool owns_desc = true;                // false: the tree is another handle's too (a group rank on rank 0's GPU, vrc_assign_octree_from)
     bool own_copy = false;                // group flag VRC_GROUP_OWN_COPIES: never share, always take the device-to-device copy path
     int32_t peer_access = -1;             // -1 same GPU as rank 0 / rank 0 itself, 1 direct peer access enabled, 0 the runtime stages the copies
     void *pinned_stage = nullptr; size_t pinned_stage_bytes = 0;   // read-back staging for a pageable destination (groups)
+    bool last_frame_boxes = false;        // the last enqueued frame was rendered with the tree's empty boxes (its descriptor-read counts are the box traversal's)
     bool last_frame_wrote_hits = false;   // d_hits belongs to the last enqueued frame (setting hit_records was on)
     uint32_t *d_attach_lookup = nullptr; uint64_t *d_attach = nullptr; uint64_t n_attach = 0;
     float *d_viewport = nullptr; float *d_image = nullptr; int32_t *d_hits = nullptr; uint8_t *d_rgba8 = nullptr;
@@ -139,13 +166,25 @@ void release(T *&p) {
     if (p) { (void)hipFree(p); p = nullptr; }
 }
 
+// the handle lets go of its tree; the arrays, the table and the boxes are freed with the last handle that holds them
 void release_tree(vrc_caster *h) {
-    release(h->d_coarse); h->coarse_log2 = 0;                      // the table describes the tree that goes away
-    release(h->d_boxes); release(h->d_box_aux); h->box_log2 = 0;
-    if (h->owns_desc) { release(h->d_desc); release(h->d_attach_lookup); release(h->d_attach); }
+    h->tree.reset();
     h->d_desc = nullptr; h->d_attach_lookup = nullptr; h->d_attach = nullptr;
     h->owns_desc = true;
     h->n_desc = 0; h->n_attach = 0; h->have_octree = false; h->validated = false;
+}
+// a fresh, unshared tree for this handle (its arrays are filled in by the caller)
+vrc_tree *new_tree(vrc_caster *h) {
+    h->tree = std::make_shared<vrc_tree>();
+    h->tree->device = h->device;
+    h->owns_desc = true;
+    return h->tree.get();
+}
+// the handle's mirrors of its tree's fields
+void mirror_tree(vrc_caster *h) {
+    const vrc_tree *t = h->tree.get();
+    h->d_desc = t ? t->d_desc : nullptr; h->n_desc = t ? t->n_desc : 0;
+    h->d_attach_lookup = t ? t->d_attach_lookup : nullptr; h->d_attach = t ? t->d_attach : nullptr; h->n_attach = t ? t->n_attach : 0;
 }
 
 int find_setting(const vrc_caster *h, const char *name) {
@@ -479,6 +518,7 @@ namespace {
 // Give every other rank of the group rank 0's tree: shared when the rank sits on the same GPU, copied device to
 // device otherwise (hipMemcpyPeerAsync: xGMI, no host staging; SURVEY 8e "peer fan-out").
 int fan_out_tree(vrc_caster *h) {
+    mirror_tree(h);
     if (!h->peers.empty()) {                                   // the copies run on the peers' streams: rank 0's tree must be complete
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -487,21 +527,25 @@ int fan_out_tree(vrc_caster *h) {
         vrc_caster *q = h->peers[i];
         release_tree(q);
         if (q->device == h->device && !q->own_copy) {
-            q->d_desc = h->d_desc; q->d_attach_lookup = h->d_attach_lookup; q->d_attach = h->d_attach;
+            q->tree = h->tree;                                 // one tree, one table, one set of boxes for the ranks of one GPU
             q->owns_desc = false;
         } else {
             HIP_TRY(h, hipSetDevice(q->device));
-            HIP_TRY(h, hipMalloc((void **)&q->d_desc, h->n_desc * sizeof(uint64_t)));
-            HIP_TRY(h, hipMemcpyPeerAsync(q->d_desc, q->device, h->d_desc, h->device, h->n_desc * sizeof(uint64_t), q->stream));
+            vrc_tree *t = new_tree(q);
+            t->n_desc = h->n_desc;
+            HIP_TRY(h, hipMalloc((void **)&t->d_desc, h->n_desc * sizeof(uint64_t)));
+            HIP_TRY(h, hipMemcpyPeerAsync(t->d_desc, q->device, h->d_desc, h->device, h->n_desc * sizeof(uint64_t), q->stream));
             if (h->d_attach_lookup && h->d_attach) {
-                HIP_TRY(h, hipMalloc((void **)&q->d_attach_lookup, h->n_desc * sizeof(uint32_t)));
-                HIP_TRY(h, hipMalloc((void **)&q->d_attach, std::max<uint64_t>(h->n_attach, 1) * sizeof(uint64_t)));
-                HIP_TRY(h, hipMemcpyPeerAsync(q->d_attach_lookup, q->device, h->d_attach_lookup, h->device, h->n_desc * sizeof(uint32_t), q->stream));
-                HIP_TRY(h, hipMemcpyPeerAsync(q->d_attach, q->device, h->d_attach, h->device,
+                t->n_attach = h->n_attach;
+                HIP_TRY(h, hipMalloc((void **)&t->d_attach_lookup, h->n_desc * sizeof(uint32_t)));
+                HIP_TRY(h, hipMalloc((void **)&t->d_attach, std::max<uint64_t>(h->n_attach, 1) * sizeof(uint64_t)));
+                HIP_TRY(h, hipMemcpyPeerAsync(t->d_attach_lookup, q->device, h->d_attach_lookup, h->device, h->n_desc * sizeof(uint32_t), q->stream));
+                HIP_TRY(h, hipMemcpyPeerAsync(t->d_attach, q->device, h->d_attach, h->device,
                                               std::max<uint64_t>(h->n_attach, 1) * sizeof(uint64_t), q->stream));
             }
         }
-        q->n_desc = h->n_desc; q->n_attach = h->n_attach; q->have_octree = true; q->validated = false;
+        mirror_tree(q);
+        q->have_octree = true; q->validated = false;
         int rc = set_setting(q, "octree_root_index", "OCTREE_ROOT_INDEX", setting_or(h, "octree_root_index", 0));
         if (rc != VRC_OK) return rc;
     }
@@ -527,11 +571,32 @@ int vrc_assign_octree(vrc_caster *h, const uint64_t *descriptors, uint64_t n, ui
     HIP_TRY(h, hipSetDevice(h->device));
     for (vrc_caster *q : h->peers) release_tree(q);
     release_tree(h);                                               // a new tree never inherits the old one's materials
-    HIP_TRY(h, hipMalloc((void **)&h->d_desc, n * sizeof(uint64_t)));
-    HIP_TRY(h, hipMemcpy(h->d_desc, descriptors, n * sizeof(uint64_t), hipMemcpyHostToDevice));
-    h->n_desc = n;
+    vrc_tree *t = new_tree(h);
+    HIP_TRY(h, hipMalloc((void **)&t->d_desc, n * sizeof(uint64_t)));
+    HIP_TRY(h, hipMemcpy(t->d_desc, descriptors, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    t->n_desc = n;
+    mirror_tree(h);
     h->have_octree = true;
     int rc = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)root_index);   // CLCaster.cpp:113
+    if (rc != VRC_OK) return rc;
+    return fan_out_tree(h);
+}
+
+// The tree another handle on the same GPU already holds, adopted instead of uploaded again: one descriptor array, one coarse
+// table, one set of empty boxes between the two (vrc_tree).  The arrays live until the last handle lets go of them.
+int vrc_assign_octree_from(vrc_caster *h, vrc_caster *src) {
+    if (!h || !src || h == src) return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_from: bad argument");
+    if (!src->tree || !src->have_octree) return fail(h, VRC_ERR_NOT_READY, "assign_octree_from: the source handle has no octree");
+    if (src->device != h->device) return fail(h, VRC_ERR_INVALID_ARGUMENT, "assign_octree_from: the handles sit on different GPUs (%d, %d)", h->device, src->device);
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::shared_ptr<vrc_tree> keep = src->tree;                    // (src may be a peer of h's own group)
+    for (vrc_caster *q : h->peers) release_tree(q);
+    release_tree(h);
+    h->tree = keep;
+    h->owns_desc = false;
+    mirror_tree(h);
+    h->have_octree = true;
+    const int rc = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", setting_or(src, "octree_root_index", 0));
     if (rc != VRC_OK) return rc;
     return fan_out_tree(h);
 }
@@ -551,33 +616,38 @@ int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_
     }
     // from here on every rank drops its old buffers first, so that a device failure half-way can never leave two ranks
     // of one frame with different materials (ranks that share rank 0's arrays just forget the pointers)
-    for (vrc_caster *q : h->peers) {
-        if (q->owns_desc) { (void)hipSetDevice(q->device); release(q->d_attach_lookup); release(q->d_attach); }
-        q->d_attach_lookup = nullptr; q->d_attach = nullptr; q->n_attach = 0; q->validated = false;
-    }
+    // (the buffers belong to the TREE: every handle that shares it renders with the new materials from its next frame on)
+    auto drop = [](vrc_caster *q) {
+        vrc_tree *t = q->tree.get();
+        if (t) { (void)hipSetDevice(t->device); release(t->d_attach_lookup); release(t->d_attach); t->n_attach = 0; }
+        mirror_tree(q);
+        q->validated = false;
+    };
+    for (vrc_caster *q : h->peers) drop(q);
+    drop(h);
     HIP_TRY(h, hipSetDevice(h->device));
-    release(h->d_attach_lookup); release(h->d_attach);
-    h->n_attach = 0; h->validated = false;
+    vrc_tree *t = h->tree.get();
     if (have) {
-        HIP_TRY(h, hipMalloc((void **)&h->d_attach_lookup, n_lookup * sizeof(uint32_t)));
-        HIP_TRY(h, hipMemcpy(h->d_attach_lookup, lookup, n_lookup * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMalloc((void **)&h->d_attach, n_attachments * sizeof(uint64_t)));
-        HIP_TRY(h, hipMemcpy(h->d_attach, attachments, n_attachments * sizeof(uint64_t), hipMemcpyHostToDevice));
-        h->n_attach = n_attachments;
+        HIP_TRY(h, hipMalloc((void **)&t->d_attach_lookup, n_lookup * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemcpy(t->d_attach_lookup, lookup, n_lookup * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMalloc((void **)&t->d_attach, n_attachments * sizeof(uint64_t)));
+        HIP_TRY(h, hipMemcpy(t->d_attach, attachments, n_attachments * sizeof(uint64_t), hipMemcpyHostToDevice));
+        t->n_attach = n_attachments;
     }
+    mirror_tree(h);
     if (h->peers.empty()) return VRC_OK;
     // ranks with their own copy of the descriptors: only the attachment buffers change
     for (vrc_caster *q : h->peers) {
-        if (!q->owns_desc) {
-            q->d_attach_lookup = h->d_attach_lookup; q->d_attach = h->d_attach; q->n_attach = h->n_attach;
-        } else if (h->d_attach_lookup && h->d_attach) {
+        vrc_tree *tq = q->tree.get();
+        if (tq != t && h->d_attach_lookup && h->d_attach) {
             HIP_TRY(h, hipSetDevice(q->device));
-            HIP_TRY(h, hipMalloc((void **)&q->d_attach_lookup, h->n_desc * sizeof(uint32_t)));
-            HIP_TRY(h, hipMalloc((void **)&q->d_attach, h->n_attach * sizeof(uint64_t)));
-            HIP_TRY(h, hipMemcpyPeer(q->d_attach_lookup, q->device, h->d_attach_lookup, h->device, h->n_desc * sizeof(uint32_t)));
-            HIP_TRY(h, hipMemcpyPeer(q->d_attach, q->device, h->d_attach, h->device, h->n_attach * sizeof(uint64_t)));
-            q->n_attach = h->n_attach;
+            HIP_TRY(h, hipMalloc((void **)&tq->d_attach_lookup, h->n_desc * sizeof(uint32_t)));
+            HIP_TRY(h, hipMalloc((void **)&tq->d_attach, h->n_attach * sizeof(uint64_t)));
+            HIP_TRY(h, hipMemcpyPeer(tq->d_attach_lookup, q->device, h->d_attach_lookup, h->device, h->n_desc * sizeof(uint32_t)));
+            HIP_TRY(h, hipMemcpyPeer(tq->d_attach, q->device, h->d_attach, h->device, h->n_attach * sizeof(uint64_t)));
+            tq->n_attach = h->n_attach;
         }
+        mirror_tree(q);
     }
     HIP_TRY(h, hipSetDevice(h->device));
     return VRC_OK;
@@ -633,22 +703,24 @@ int vrc_assign_octree_file(vrc_caster *h, const char *path, uint32_t *dim) {
     int rc = VRC_OK;
     if (chunk < 4096 || hipHostMalloc(&stage[0], chunk, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&stage[1], chunk, hipHostMallocDefault) != hipSuccess)
         rc = fail(h, VRC_ERR_OUT_OF_MEMORY, "assign_octree_file: no pinned staging memory");
-    if (rc == VRC_OK && hipMalloc((void **)&h->d_desc, n * sizeof(uint64_t)) != hipSuccess)
+    vrc_tree *t = new_tree(h);
+    if (rc == VRC_OK && hipMalloc((void **)&t->d_desc, n * sizeof(uint64_t)) != hipSuccess)
         rc = fail(h, VRC_ERR_OUT_OF_MEMORY, "assign_octree_file: %llu descriptors do not fit in device memory", (unsigned long long)n);
-    if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_desc, n * sizeof(uint64_t), stage, chunk, nullptr, 0);
+    if (rc == VRC_OK) rc = stream_to_device(h, f, t->d_desc, n * sizeof(uint64_t), stage, chunk, nullptr, 0);
     if (rc == VRC_OK && (flags & 1u)) {
-        if (hipMalloc((void **)&h->d_attach_lookup, n * sizeof(uint32_t)) != hipSuccess ||
-            hipMalloc((void **)&h->d_attach, (na ? na : 1) * sizeof(uint64_t)) != hipSuccess)
+        if (hipMalloc((void **)&t->d_attach_lookup, n * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void **)&t->d_attach, (na ? na : 1) * sizeof(uint64_t)) != hipSuccess)
             rc = fail(h, VRC_ERR_OUT_OF_MEMORY, "assign_octree_file: attachment buffers do not fit in device memory");
-        if (rc == VRC_OK && na == 0 && hipMemset(h->d_attach, 0x05, sizeof(uint64_t)) != hipSuccess)
+        if (rc == VRC_OK && na == 0 && hipMemset(t->d_attach, 0x05, sizeof(uint64_t)) != hipSuccess)
             rc = fail(h, VRC_ERR_DEVICE, "assign_octree_file: memset failed");
-        if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_attach_lookup, n * sizeof(uint32_t), stage, chunk, check_lookup_chunk, na);
-        if (rc == VRC_OK) rc = stream_to_device(h, f, h->d_attach, na * sizeof(uint64_t), stage, chunk, nullptr, 0);
+        if (rc == VRC_OK) rc = stream_to_device(h, f, t->d_attach_lookup, n * sizeof(uint32_t), stage, chunk, check_lookup_chunk, na);
+        if (rc == VRC_OK) rc = stream_to_device(h, f, t->d_attach, na * sizeof(uint64_t), stage, chunk, nullptr, 0);
     }
     fclose(f);
     for (int i = 0; i < 2; i++) if (stage[i]) (void)hipHostFree(stage[i]);
     if (rc != VRC_OK) { release_tree(h); return rc; }
-    h->n_desc = n; h->n_attach = (flags & 1u) ? std::max<uint64_t>(na, 1) : 0;
+    t->n_desc = n; t->n_attach = (flags & 1u) ? std::max<uint64_t>(na, 1) : 0;
+    mirror_tree(h);
     h->have_octree = true;
     rc = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)root);   // CLCaster.cpp:113
     if (rc != VRC_OK) return rc;
@@ -674,7 +746,8 @@ int vrc_build_shell_terrain(vrc_caster *h, uint32_t depth, uint64_t seed, int32_
     if (info) *info = bi;
     if (rc != VRC_OK) return fail(h, rc, "build_shell_terrain: %s", err.c_str());
     if (count_only) return VRC_OK;
-    h->d_desc = d; h->n_desc = bi.n_descriptors; h->have_octree = true;
+    { vrc_tree *t = new_tree(h); t->d_desc = d; t->n_desc = bi.n_descriptors; mirror_tree(h); }
+    h->have_octree = true;
     const int rs = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)bi.root_index);
     if (rs != VRC_OK) return rs;
     return fan_out_tree(h);
@@ -701,7 +774,8 @@ int vrc_build_heightfield(vrc_caster *h, uint32_t depth, const uint16_t *hi, con
     if (info) *info = bi;
     if (rc != VRC_OK) return fail(h, rc, "build_heightfield: %s", err.c_str());
     if (count_only) return VRC_OK;
-    h->d_desc = d; h->n_desc = bi.n_descriptors; h->have_octree = true;
+    { vrc_tree *t = new_tree(h); t->d_desc = d; t->n_desc = bi.n_descriptors; mirror_tree(h); }
+    h->have_octree = true;
     const int rs = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)bi.root_index);
     if (rs != VRC_OK) return rs;
     return fan_out_tree(h);
@@ -730,8 +804,13 @@ int vrc_build_dense_grid(vrc_caster *h, uint32_t depth, const int8_t *grid, uint
     if (info) *info = bi;
     if (rc != VRC_OK) return fail(h, rc, "build_dense_grid: %s", err.c_str());
     if (count_only) return VRC_OK;
-    h->d_desc = d; h->n_desc = bi.n_descriptors; h->have_octree = true;
-    h->d_attach_lookup = lookup; h->d_attach = attach; h->n_attach = n_attach;
+    {
+        vrc_tree *t = new_tree(h);
+        t->d_desc = d; t->n_desc = bi.n_descriptors;
+        t->d_attach_lookup = lookup; t->d_attach = attach; t->n_attach = n_attach;
+        mirror_tree(h);
+    }
+    h->have_octree = true;
     const int rs = set_setting(h, "octree_root_index", "OCTREE_ROOT_INDEX", (int64_t)bi.root_index);
     if (rs != VRC_OK) return rs;
     return fan_out_tree(h);
@@ -1003,52 +1082,84 @@ int compute_async_one(vrc_caster *h) {
     }
     p.counters = h->d_partials;
     if (svo) {
-        // the levels above coarse_log2 as a dense table (setting coarse_log2: -1 = by depth, 0 = none), read by both SVO kernels;
-        // built here on first use and whenever the tree, its root or its depth changed
+        // What the kernels derive from the tree lives WITH the tree (vrc_tree): built here on first use, by the first handle that
+        // needs it, and whenever the root, the depth or the level asked for changed; shared by every handle that shares the array.
+        // Both structures are optional accelerations: when their memory cannot be had the frame is rendered without them (the
+        // table-less / box-less kernel instances), the reason is kept in vrc_tree::note and reported by vrc_memory_usage2.
+        vrc_tree *t = h->tree.get();
+        std::lock_guard<std::mutex> lock(t->guard);
+        // the levels above coarse_log2 as a dense table (setting coarse_log2: -1 = by depth and tree size, 0 = none), read by both
+        // SVO kernels.  By default the finest level of the depth rule whose table is at most 16 x the descriptor array: a sparse
+        // tree in a large map does not get a table hundreds of times its own size
         int64_t lc = setting_or(h, "coarse_log2", -1);
-        if (lc < 0) lc = vrc::coarse_level_for_depth(p.log2_dim);
-        lc = std::min<int64_t>(lc, std::min(p.log2_dim - 2, 10));
-        if (lc >= 1 && h->n_desc < (1ULL << 43)) {
-            if (!h->d_coarse || h->coarse_log2 != (int)lc || h->coarse_root != p.root_index || h->coarse_depth != p.log2_dim) {
-                release(h->d_coarse);
-                h->coarse_log2 = 0;
-                HIP_TRY(h, hipMalloc((void **)&h->d_coarse, sizeof(uint64_t) << (3 * lc)));
-                HIP_TRY(h, vrc::launch_coarse_build(h->d_desc, p.root_index, p.log2_dim, (int)lc, h->d_coarse, h->stream));
-                h->coarse_log2 = (int)lc; h->coarse_root = p.root_index; h->coarse_depth = p.log2_dim;
-            }
-            p.coarse = h->d_coarse; p.coarse_log2 = (int32_t)lc;
-        } else {
-            release(h->d_coarse); h->coarse_log2 = 0;             // the setting went to "none": the table goes too
+        if (lc < 0) {
+            lc = vrc::coarse_level_for_depth(p.log2_dim);
+            while (lc >= 1 && ((uint64_t)sizeof(uint64_t) << (3 * lc)) > 16 * sizeof(uint64_t) * t->n_desc && ((uint64_t)sizeof(uint64_t) << (3 * lc)) > (1u << 20)) lc--;
         }
-        // the empty boxes (setting empty_boxes: -1 = when the tree is small enough for them, 0 = never, 1 = always): 32 bytes per
-        // descriptor + 4 per table cell, built here on first use like the table they hang on; exact mode only
-        const int64_t want_boxes = setting_or(h, "empty_boxes", -1);
-        const bool box_ok = p.coarse != nullptr && p.stepping_mode == 0 && p.log2_dim <= 19 && h->n_desc < (1ULL << 31);
-        if (box_ok && (want_boxes > 0 || (want_boxes < 0 && h->n_desc <= (1ULL << 28)))) {
-            if (!h->d_boxes || h->box_log2 != (int)lc || h->box_root != p.root_index || h->box_depth != p.log2_dim) {
-                release(h->d_boxes); release(h->d_box_aux);
-                h->box_log2 = 0;
-                uint64_t *pos_tmp = nullptr;
-                HIP_TRY(h, hipMalloc((void **)&h->d_boxes, sizeof(uint32_t) * 8 * h->n_desc));
-                HIP_TRY(h, hipMalloc((void **)&h->d_box_aux, sizeof(uint32_t) << (3 * lc)));
-                HIP_TRY(h, hipMalloc((void **)&pos_tmp, sizeof(uint64_t) * h->n_desc));
-                hipEvent_t e0, e1;
-                HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
-                HIP_TRY(h, hipEventRecord(e0, h->stream));
-                const hipError_t be = vrc::launch_box_build(h->d_desc, h->n_desc, p.root_index, p.log2_dim, (int)lc, pos_tmp, h->d_boxes, h->d_box_aux, h->stream);
-                HIP_TRY(h, hipEventRecord(e1, h->stream));
-                const hipError_t se = hipStreamSynchronize(h->stream);
-                float ms = 0.f;
-                (void)hipEventElapsedTime(&ms, e0, e1);
-                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-                (void)hipFree(pos_tmp);
-                HIP_TRY(h, be); HIP_TRY(h, se);
-                h->box_build_seconds = ms * 1e-3;
-                h->box_log2 = (int)lc; h->box_root = p.root_index; h->box_depth = p.log2_dim;
+        lc = std::min<int64_t>(lc, std::min(p.log2_dim - 2, 10));
+        if (lc >= 1 && t->n_desc < (1ULL << 43)) {
+            if (!t->d_coarse || t->coarse_log2 != (int)lc || t->coarse_root != p.root_index || t->coarse_depth != p.log2_dim) {
+                release(t->d_coarse);
+                release(t->d_boxes); release(t->d_box_aux); t->box_log2 = 0;   // (the boxes' parallel word belongs to the table's cells)
+                t->coarse_log2 = 0;
+                if (!t->coarse_gave_up) {
+                    hipError_t e = hipMalloc((void **)&t->d_coarse, sizeof(uint64_t) << (3 * lc));
+                    if (e == hipSuccess) e = vrc::launch_coarse_build(t->d_desc, p.root_index, p.log2_dim, (int)lc, t->d_coarse, h->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);          // other handles read it from their own streams
+                    if (e != hipSuccess) {
+                        (void)hipGetLastError();
+                        release(t->d_coarse);
+                        t->coarse_gave_up = true;
+                        t->note = std::string("no coarse table (level ") + std::to_string(lc) + "): " + hipGetErrorString(e) + "; ";
+                    } else {
+                        t->coarse_log2 = (int)lc; t->coarse_root = p.root_index; t->coarse_depth = p.log2_dim;
+                    }
+                }
             }
-            p.boxes = h->d_boxes; p.box_aux = h->d_box_aux;
-        } else if (h->d_boxes && want_boxes == 0) {
-            release(h->d_boxes); release(h->d_box_aux); h->box_log2 = 0;   // the setting went to "never": the boxes go too
+            if (t->d_coarse) { p.coarse = t->d_coarse; p.coarse_log2 = (int32_t)lc; }
+        } else if (t->d_coarse) {
+            release(t->d_coarse); t->coarse_log2 = 0;             // the setting went to "none": the table goes too
+            release(t->d_boxes); release(t->d_box_aux); t->box_log2 = 0;
+        }
+        // the empty boxes (empty_boxes.hip; setting empty_boxes: -1 = when the tree is small enough for them, 0 = never, 1 = always):
+        // 32 bytes per descriptor + 4 per table cell, built on first use like the table they hang on; exact mode only
+        const int64_t want_boxes = setting_or(h, "empty_boxes", -1);
+        const bool box_ok = p.coarse != nullptr && p.stepping_mode == 0 && p.log2_dim <= 19 && t->n_desc < (1ULL << 31);
+        if (box_ok && (want_boxes > 0 || (want_boxes < 0 && t->n_desc <= (1ULL << 28)))) {
+            if (!t->d_boxes || t->box_log2 != (int)lc || t->box_root != p.root_index || t->box_depth != p.log2_dim) {
+                release(t->d_boxes); release(t->d_box_aux);
+                t->box_log2 = 0;
+                if (!t->boxes_gave_up) {
+                    uint64_t *pos_tmp = nullptr;
+                    hipEvent_t e0 = nullptr, e1 = nullptr;
+                    float ms = 0.f;
+                    hipError_t e = hipMalloc((void **)&t->d_boxes, sizeof(uint32_t) * 8 * t->n_desc);
+                    if (e == hipSuccess) e = hipMalloc((void **)&t->d_box_aux, sizeof(uint32_t) << (3 * lc));
+                    if (e == hipSuccess) e = hipMalloc((void **)&pos_tmp, sizeof(uint64_t) * t->n_desc);
+                    if (e == hipSuccess) e = hipEventCreate(&e0);
+                    if (e == hipSuccess) e = hipEventCreate(&e1);
+                    if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
+                    if (e == hipSuccess) e = vrc::launch_box_build(t->d_desc, t->n_desc, p.root_index, p.log2_dim, (int)lc, pos_tmp, t->d_boxes, t->d_box_aux, h->stream);
+                    if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                    if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+                    if (e0) (void)hipEventDestroy(e0);
+                    if (e1) (void)hipEventDestroy(e1);
+                    if (pos_tmp) (void)hipFree(pos_tmp);
+                    if (e != hipSuccess) {
+                        (void)hipGetLastError();
+                        release(t->d_boxes); release(t->d_box_aux);
+                        t->boxes_gave_up = true;
+                        t->note += std::string("no empty boxes: ") + hipGetErrorString(e) + "; ";
+                    } else {
+                        t->box_build_seconds = ms * 1e-3;
+                        t->box_log2 = (int)lc; t->box_root = p.root_index; t->box_depth = p.log2_dim;
+                    }
+                }
+            }
+            if (t->d_boxes) { p.boxes = t->d_boxes; p.box_aux = t->d_box_aux; }
+        } else if (t->d_boxes && want_boxes == 0 && h->tree.use_count() == 1) {
+            release(t->d_boxes); release(t->d_box_aux); t->box_log2 = 0;   // the setting went to "never" and nobody else renders this tree
         }
     }
     // exact closed-form jumps: on from depth 12; the threshold depends on where the Euclid tables live (LDS when stack + tables
@@ -1066,6 +1177,7 @@ int compute_async_one(vrc_caster *h) {
         if (rc != VRC_OK) return rc;
         p.jump_cache = h->d_jump_cache; p.jump_slots = h->d_jump_slots; p.jump_slot_count = h->jump_slot_count;
     }
+    h->last_frame_boxes = p.boxes != nullptr;
     h->last_blocks = nblocks;
     h->frames_enqueued++;
 
@@ -1202,21 +1314,50 @@ int vrc_unpin_host_buffer(void *p) {
 // self-check of the empty boxes the last frame used: pseudo-random voxels inside pseudo-random boxes, looked up in the tree
 int vrc_empty_boxes_check(vrc_caster *h, uint64_t samples, uint64_t seed, uint64_t *boxes_sampled, uint64_t *solid_voxels, double *build_seconds) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
-    if (!h->d_boxes || !h->d_desc) return fail(h, VRC_ERR_NOT_READY, "empty_boxes_check: no boxes (setting empty_boxes, or no frame computed yet)");
+    vrc_tree *t = h->tree.get();
+    if (!t || !t->d_boxes || !t->d_desc) return fail(h, VRC_ERR_NOT_READY, "empty_boxes_check: no boxes (setting empty_boxes, or no frame computed yet)");
     HIP_TRY(h, hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lock(t->guard);
     uint64_t *pos = nullptr; unsigned long long *res = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&pos, sizeof(uint64_t) * h->n_desc));
+    HIP_TRY(h, hipMalloc((void **)&pos, sizeof(uint64_t) * t->n_desc));
     hipError_t e = hipMalloc((void **)&res, 2 * sizeof(unsigned long long));
     unsigned long long out[2] = {0, 0};
-    if (e == hipSuccess) e = vrc::launch_box_positions(h->d_desc, h->n_desc, h->box_root, h->box_depth, pos, h->stream);
-    if (e == hipSuccess) e = vrc::launch_box_check(h->d_desc, h->n_desc, h->box_root, h->box_depth, pos, h->d_boxes, samples, seed, res, h->stream);
+    if (e == hipSuccess) e = vrc::launch_box_positions(t->d_desc, t->n_desc, t->box_root, t->box_depth, pos, h->stream);
+    if (e == hipSuccess) e = vrc::launch_box_check(t->d_desc, t->n_desc, t->box_root, t->box_depth, pos, t->d_boxes, samples, seed, res, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMemcpy(out, res, sizeof(out), hipMemcpyDeviceToHost);
     (void)hipFree(pos); (void)hipFree(res);
     HIP_TRY(h, e);
     if (boxes_sampled) *boxes_sampled = out[0];
     if (solid_voxels) *solid_voxels = out[1];
-    if (build_seconds) *build_seconds = h->box_build_seconds;
+    if (build_seconds) *build_seconds = t->box_build_seconds;
+    return VRC_OK;
+}
+
+// vrc_memory_usage with a size-versioned struct (the caller says how large ITS struct is; never more than that is written)
+int vrc_memory_usage2(vrc_caster *h, int32_t rank, vrc_memory2 *out) {
+    if (!h || !out || rank < 0 || rank > (int32_t)h->peers.size() || out->struct_size < sizeof(uint32_t)) return VRC_ERR_INVALID_ARGUMENT;
+    const vrc_caster *q = rank == 0 ? h : h->peers[rank - 1];
+    vrc_memory2 m;
+    memset(&m, 0, sizeof(m));
+    const size_t npix = q->d_viewport ? (size_t)q->width * (size_t)std::max(q->buffer_rows, 1) : 0;
+    m.device = q->device; m.rows = q->buffer_rows;
+    m.viewport_bytes = 16 * npix; m.image_bytes = 16 * npix; m.hit_bytes = q->d_hits ? 32 * npix : 0;
+    m.octree_bytes = q->d_desc ? q->n_desc * 8 + (q->d_attach_lookup ? q->n_desc * 4 + std::max<uint64_t>(q->n_attach, 1) * 8 : 0) : 0;
+    m.octree_shared = q->owns_desc ? 0 : 1;
+    m.peer_access = q->peer_access;
+    if (const vrc_tree *t = q->tree.get()) {
+        m.tree_holders = (int32_t)q->tree.use_count();
+        m.coarse_log2 = t->d_coarse ? t->coarse_log2 : 0;
+        m.coarse_bytes = t->d_coarse ? (uint64_t)sizeof(uint64_t) << (3 * t->coarse_log2) : 0;
+        m.empty_boxes = q->last_frame_boxes ? 1 : 0;
+        m.box_bytes = t->d_boxes ? (uint64_t)sizeof(uint32_t) * 8 * t->n_desc + ((uint64_t)sizeof(uint32_t) << (3 * t->box_log2)) : 0;
+        m.box_build_seconds = t->box_build_seconds;
+        snprintf(m.note, sizeof(m.note), "%s", t->note.c_str());
+    }
+    const uint32_t n = std::min<uint32_t>(out->struct_size, (uint32_t)sizeof(m));
+    m.struct_size = n;
+    memcpy(out, &m, n);
     return VRC_OK;
 }
 
@@ -1233,7 +1374,8 @@ int vrc_memory_usage(vrc_caster *h, int32_t rank, vrc_memory *out) {
     out->octree_bytes = q->d_desc ? q->n_desc * 8 + (q->d_attach_lookup ? q->n_desc * 4 + std::max<uint64_t>(q->n_attach, 1) * 8 : 0) : 0;
     out->octree_shared = q->owns_desc ? 0 : 1;
     out->peer_access = q->peer_access;
-    out->coarse_bytes = q->d_coarse ? (uint64_t)sizeof(uint64_t) << (3 * q->coarse_log2) : 0;
+    const vrc_tree *t = q->tree.get();
+    out->coarse_bytes = (t && t->d_coarse) ? (uint64_t)sizeof(uint64_t) << (3 * t->coarse_log2) : 0;
     return VRC_OK;
 }
 
