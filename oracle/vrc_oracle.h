@@ -134,7 +134,8 @@ typedef struct {
                                             stateless node-exit jumps, see raycast_pixel / jump_step in vrc_oracle.c   */
     int32_t         coarse_log2;         /* mode B only (round 4): the levels above this one are a dense table in the product
                                             (raycast_jump_kernel.hip coarse_build_kernel); -1: by depth (n >= 5: min(n - 2, 9),
-                                            else none), 0: none.  Changes the descriptor-read count only, see svo_locate     */
+                                            else none) and tree size (the finest such level whose table is at most 16 x the descriptor
+                                            array or below 1 MiB), 0: none.  Changes the descriptor-read count only, see svo_locate     */
     /* optional paged descriptor source (see ORC_PAGE_SIZE): when desc_page_fetch is set, `descriptors` is not read;
      * desc_pages is a zero-initialised table of ceil(n_descriptors / ORC_PAGE_SIZE) pointers the oracle fills */
     const uint64_t  **desc_pages;
