@@ -431,6 +431,57 @@ def test_oracle_matches_the_reference_kernel_vectors(path, atlas):
     refcompare.compare(s, w, h, z["records"], oimg, ohits, octr, verbose=False)
 
 
+REF_OCT_VOX = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ref_get_oct_vox_*.npz")))
+REF_VIEW_LIGHT = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ref_view_light_*.npz")))
+
+
+@pytest.mark.skipif(not REF_OCT_VOX, reason="tests/golden/ref_get_oct_vox_*.npz missing (tests/make_reference_pin_golden.py, GPU box)")
+@pytest.mark.parametrize("path", REF_OCT_VOX, ids=[os.path.basename(p)[4:-4] for p in REF_OCT_VOX])
+def test_oracle_matches_the_reference_get_oct_vox_vectors(path):
+    """outputs of the reference's own get_oct_vox (ray_caster_kernel.cl:140-251, compiled unmodified for
+    gfx950 and run on an MI355X by tests/make_reference_pin_golden.py) -- every field the function returns, for every voxel of
+    the 16^3 trees and 4000 random voxels of the 64^3 (far pointers + page header), 128^3 and 256^3 trees -- replayed against
+    orc_get_oct_vox on every CPU run.  The tree is rebuilt from the stored seed by the oracle's builder."""
+    z = np.load(path)
+    dim, seed = int(z["dim"]), int(z["seed"])
+    rng = np.random.default_rng(seed)
+    grid = (rng.random(dim ** 3) < float(z["density"])).astype(np.int8) * 5
+    buf, root = orc.octree_generate(grid, dim)
+    found_any = False
+    for p, o in zip(z["positions"], z["out"]):
+        ts = orc.get_oct_vox(p, buf, root, dim)
+        mine = [ts.found, ts.scale, ts.resolution, ts.parent_stack_position, *ts.sub_oct_pos, *ts.oct_pos,
+                ts.current_descriptor_index & 0xffffffff, ts.current_descriptor_index >> 32,
+                ts.current_descriptor & 0xffffffff, ts.current_descriptor >> 32]
+        assert [int(v) & 0xffffffff for v in o[:14]] == [int(v) & 0xffffffff for v in mine], (p, o[:14], mine)
+        k = ts.scale + 1
+        assert list(o[14:14 + k]) == [ts.idx_stack[j] for j in range(k)]
+        k = ts.parent_stack_position + 1
+        assert [int(v) & 0xffffffff for v in o[22:22 + k]] == [ts.parent_stack_index[j] & 0xffffffff for j in range(k)]
+        assert [int(v) & 0xffffffff for v in o[30:30 + k]] == [ts.parent_stack[j] & 0xffffffff for j in range(k)]
+        found_any = found_any or bool(ts.found)
+        assert bool(ts.found) == bool(grid[p[0] + dim * (p[1] + dim * p[2])])     # Octree::Validate, Octree.cpp:329-352
+    assert found_any
+
+
+@pytest.mark.skipif(not REF_VIEW_LIGHT, reason="tests/golden/ref_view_light_*.npz missing (tests/make_reference_pin_golden.py, GPU box)")
+@pytest.mark.parametrize("path", REF_VIEW_LIGHT, ids=[os.path.basename(p)[4:-4] for p in REF_VIEW_LIGHT])
+def test_oracle_matches_the_reference_view_light_vectors(path):
+    """Outputs of the reference's own view_light (ray_caster_kernel.cl:78-99) on 6000 seeded cases incl. ties and the zero-light
+    early return, both builds (the reference's fast-math flags, and without them).  The reference's normalize / fast_length are
+    the OpenCL library's 1-2 ulp approximations, so bit equality with the IEEE restatement is not defined; what IS measured on
+    these fixed cases is asserted: worst relative difference below 4e-5, >= 99.9 % within BASELINE's 1e-5, most bit-identical."""
+    z = np.load(path)
+    cases, mask, out = z["cases"], z["mask"], z["out"]
+    mine = np.stack([orc.view_light(c[0:4], c[4:7], c[7:11], c[11:14], m) for c, m in zip(cases, mask)])
+    assert np.isfinite(out).all() and (out[:50] == 0).all() and (mine[:50] == 0).all()
+    rel = np.abs(mine - out) / np.maximum(np.abs(out), 1e-6)
+    ulp = np.abs(mine.view(np.int32).astype(np.int64) - out.view(np.int32).astype(np.int64))
+    assert rel.max() <= 4e-5, f"max relative difference {rel.max():.3g}"
+    assert (rel <= 1e-5).mean() >= 0.999
+    assert np.median(rel) == 0.0 and (ulp == 0).mean() > 0.5
+
+
 def test_oracle_mode_b_coarse_table_restated_reads():
     """The coarse top table of round 4 as the oracle restates it for mode B (svo_locate_from): one read stands for the descent
     from the root to the table's level.  Everything but the read count is the plain traversal's -- image, hit voxel, face,

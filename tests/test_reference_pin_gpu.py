@@ -76,7 +76,7 @@ def test_view_light_of_the_oracle_matches_the_reference_function(probe, code_obj
     ulp = np.abs(mine.view(np.int32).astype(np.int64) - out.view(np.int32).astype(np.int64))
     print(f"view_light vs {code_object}: max rel {rel.max():.3g}, within 1e-5 {float((rel <= 1e-5).mean()):.5f}, "
           f"max ulp {int(ulp.max())}, bit-identical {float((ulp == 0).mean()):.3f}")
-    assert rel.max() <= 1e-4, f"max relative difference {rel.max():.3g}"
+    assert rel.max() <= 4e-5, f"max relative difference {rel.max():.3g}"     # measured on these seeded cases: 3.1e-5 (both builds)
     assert (rel <= 1e-5).mean() >= 0.999                                  # BASELINE north_star tolerance for RGB
     assert np.median(rel) == 0.0 and (ulp == 0).mean() > 0.5
 
