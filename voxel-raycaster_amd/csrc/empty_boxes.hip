@@ -24,6 +24,10 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <chrono>
 
 #include "vrc_params.h"
 
@@ -89,30 +93,56 @@ __device__ __forceinline__ unsigned overlap_mask(int ox, int oy, int oz, int hal
 }
 
 // Does the tree hold a solid voxel inside [lo, hi)?  (the region lies inside the map and is not empty)
-__device__ bool region_is_empty(const uint64_t *__restrict__ descriptors, uint64_t root_index, int n, const int lo[3], const int hi[3]) {
+// The search starts at the deepest ANCESTOR of the asking node whose cube holds the whole region (path[level] = the entry of the
+// ancestor at that level, (px, py, pz) a voxel of the node): a slab next to a small node near a surface lies within the node's
+// parent or grandparent, and a walk from the root would spend ten dependent loads on getting there (the depth-12 build: 1.52 -> 1.12 s).
+__device__ bool region_is_empty(const uint64_t *__restrict__ descriptors, const uint64_t *path, int path_levels, int px, int py, int pz,
+                                int n, const int lo[3], const int hi[3]) {
+    // the node on top of the stack lives in registers (entry, children still to look at, origin); what is pushed when the search
+    // descends is the parent's entry and its remaining children + the slot taken, from which the origin comes back on the way up
     uint64_t st_entry[kMaxLevels];
-    int st_x[kMaxLevels], st_y[kMaxLevels], st_z[kMaxLevels];
-    unsigned st_todo[kMaxLevels];
-    int level = 0;
-    st_entry[0] = bx_entry(descriptors, root_index, descriptors[root_index]);
-    st_x[0] = st_y[0] = st_z[0] = 0;
-    st_todo[0] = overlap_mask(0, 0, 0, 1 << (n - 1), lo, hi) & (unsigned)st_entry[0] & 0xffu;
-    while (level >= 0) {
-        const unsigned todo = st_todo[level];
-        if (!todo) { level--; continue; }
+    unsigned st_rest[kMaxLevels];                          // bits 0-7 children still to do, 8-10 the slot the search went down into
+    // bits in which some corner of the region differs from the node's voxel: the ancestor at level a has a cube of 2^(n - a) voxels
+    const unsigned diff = (unsigned)((lo[0] ^ px) | ((hi[0] - 1) ^ px) | (lo[1] ^ py) | ((hi[1] - 1) ^ py) | (lo[2] ^ pz) | ((hi[2] - 1) ^ pz));
+    int a = n - (32 - __clz((int)diff));                  // (diff == 0: n)
+    a = a < path_levels - 1 ? a : path_levels - 1;
+    a = a < 0 ? 0 : a;
+    const int base = a;
+    const int amask = ~((1 << (n - a)) - 1);
+    int level = a;
+    uint64_t e = path[a];
+    int ox = px & amask, oy = py & amask, oz = pz & amask;
+    unsigned todo = overlap_mask(ox, oy, oz, 1 << (n - a - 1), lo, hi) & (unsigned)e & 0xffu;
+#ifndef VRC_BOX_QUERY_BUDGET
+#define VRC_BOX_QUERY_BUDGET 4096
+#endif
+    // (a query gives up -- "not empty", the side stops growing -- after this many descents: a bound on what one thread can cost)
+    int budget = VRC_BOX_QUERY_BUDGET;
+    for (;;) {
+        if (!todo) {
+            if (level == base) return true;
+            level--;
+            e = st_entry[level];
+            const unsigned rest = st_rest[level];
+            todo = rest & 0xffu;
+            const int k = (int)(rest >> 8) & 7, half = 1 << (n - level - 1);
+            ox -= (k & 1) ? half : 0; oy -= (k & 2) ? half : 0; oz -= (k & 4) ? half : 0;
+            continue;
+        }
         const int k = __ffs((int)todo) - 1;
-        st_todo[level] = todo & (todo - 1u);
-        const uint64_t e = st_entry[level];
+        todo &= todo - 1u;
         const int half = 1 << (n - level - 1);
         if ((((unsigned)e >> 8) & (1u << k)) || half == 1) return false;      // a solid leaf / voxel that meets the region
+        if (--budget < 0) return false;
         const uint64_t child = (e >> 16) + (uint64_t)(__popc((unsigned)e & 0xffu & ((2u << k) - 1u)) - 1);
         const uint64_t ce = bx_entry(descriptors, child, descriptors[child]);
-        const int cx = st_x[level] + ((k & 1) ? half : 0), cy = st_y[level] + ((k & 2) ? half : 0), cz = st_z[level] + ((k & 4) ? half : 0);
+        const int cx = ox + ((k & 1) ? half : 0), cy = oy + ((k & 2) ? half : 0), cz = oz + ((k & 4) ? half : 0);
+        const unsigned ctodo = overlap_mask(cx, cy, cz, half >> 1, lo, hi) & (unsigned)ce & 0xffu;
+        if (!ctodo) continue;                             // nothing of the child meets the region: no need to go down
+        st_entry[level] = e; st_rest[level] = todo | ((unsigned)k << 8);
         level++;
-        st_entry[level] = ce; st_x[level] = cx; st_y[level] = cy; st_z[level] = cz;
-        st_todo[level] = overlap_mask(cx, cy, cz, half >> 1, lo, hi) & (unsigned)ce & 0xffu;
+        e = ce; ox = cx; oy = cy; oz = cz; todo = ctodo;
     }
-    return true;
 }
 
 __global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64_t n_desc, uint64_t root_index, int n,
@@ -128,15 +158,29 @@ __global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64
         if (!(valid & (1u << k))) {
             const int level = (int)(ps >> kPosLevelShift);
             const int b = n - level - 1, s = 1 << b, dim = 1 << n;
+            const int nx = (int)(ps & ((1u << kPosBits) - 1u)), ny = (int)((ps >> kPosBits) & ((1u << kPosBits) - 1u)), nz = (int)((ps >> (2 * kPosBits)) & ((1u << kPosBits) - 1u));
+            // the entries of the descriptor's ancestors and its own, root first (the canonical descent toward the node)
+            uint64_t path[kMaxLevels];
+            path[0] = bx_entry(descriptors, root_index, descriptors[root_index]);
+            for (int l = 0; l < level; l++) {
+                const int bb = n - l - 1;
+                const int i = ((nx >> bb) & 1) | (((ny >> bb) & 1) << 1) | (((nz >> bb) & 1) << 2);
+                const uint64_t e = path[l];
+                const uint64_t child = (e >> 16) + (uint64_t)(__popc((unsigned)e & 0xffu & ((2u << i) - 1u)) - 1);
+                path[l + 1] = bx_entry(descriptors, child, descriptors[child]);
+            }
             int lo[3], hi[3];
-            lo[0] = (int)(ps & ((1u << kPosBits) - 1u)) + ((k & 1) ? s : 0);
-            lo[1] = (int)((ps >> kPosBits) & ((1u << kPosBits) - 1u)) + ((k & 2) ? s : 0);
-            lo[2] = (int)((ps >> (2 * kPosBits)) & ((1u << kPosBits) - 1u)) + ((k & 4) ? s : 0);
+            lo[0] = nx + ((k & 1) ? s : 0);
+            lo[1] = ny + ((k & 2) ? s : 0);
+            lo[2] = nz + ((k & 4) ? s : 0);
             for (int a = 0; a < 3; a++) hi[a] = lo[a] + s;
             const int org_lo[3] = {lo[0], lo[1], lo[2]}, org_hi[3] = {hi[0], hi[1], hi[2]};
             unsigned code[6] = {0, 0, 0, 0, 0, 0};          // -x -y -z +x +y +z
-            unsigned alive = 0x3fu;
-            // the sides in turn, z first (open sky above a terrain costs nothing to claim)
+            unsigned stride[6] = {1, 1, 1, 1, 1, 1};        // code steps the side tries next: doubled while it succeeds, halved from its first failure on
+            unsigned alive = 0x3fu, doubling = 0x3fu;
+            // the sides in turn, z first (open sky above a terrain costs nothing to claim).  A side gallops: 1, 2, 4, ... code steps
+            // per turn while the slab is empty, then a binary search back from the first slab that is not -- at most ten queries a
+            // side instead of thirty-one single steps (the build of the depth-12 scene: 1.09 -> s)
             const int order[6] = {5, 2, 3, 0, 4, 1};
             while (alive) {
                 for (int oi = 0; oi < 6; oi++) {
@@ -144,7 +188,8 @@ __global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64
                     if (!(alive & (1u << side))) continue;
                     const int a = side % 3;
                     const bool positive = side >= 3;
-                    const unsigned next = code[side] + 1u;
+                    unsigned next = code[side] + stride[side];
+                    if (next > 31u && code[side] < 31u) next = 31u;
                     // the box already reaches the map's edge on this side, or the code is exhausted
                     if (next > 31u || (positive ? hi[a] >= dim : lo[a] <= 0)) { alive &= ~(1u << side); continue; }
                     const int ext = box_decode(next) << b;
@@ -152,11 +197,16 @@ __global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64
                     int new_edge;
                     if (positive) { new_edge = org_hi[a] + ext; if (new_edge > dim) new_edge = dim; slo[a] = hi[a]; shi[a] = new_edge; }
                     else { new_edge = org_lo[a] - ext; if (new_edge < 0) new_edge = 0; shi[a] = lo[a]; slo[a] = new_edge; }
-                    if (region_is_empty(descriptors, root_index, n, slo, shi)) {
+                    if (region_is_empty(descriptors, path, level + 1, nx, ny, nz, n, slo, shi)) {
                         code[side] = next;
                         if (positive) hi[a] = new_edge; else lo[a] = new_edge;
-                    } else {
+                        if (doubling & (1u << side)) stride[side] <<= 1;
+                        else if ((stride[side] >>= 1) == 0) alive &= ~(1u << side);
+                    } else if (stride[side] == 1) {
                         alive &= ~(1u << side);
+                    } else {
+                        stride[side] >>= 1;
+                        doubling &= ~(1u << side);
                     }
                 }
             }
@@ -188,7 +238,7 @@ __global__ void box_aux_kernel(const uint64_t *__restrict__ descriptors, uint64_
         cur = bx_entry(descriptors, own, descriptors[own]);
         top++;
     }
-    aux[cell] = out;
+    aux[coarse_index((unsigned)(cell & ((1u << lc) - 1u)), (unsigned)((cell >> lc) & ((1u << lc) - 1u)), (unsigned)(cell >> (2 * lc)), lc)] = out;
 }
 
 // self-check: pseudo-random voxels inside the boxes must be empty in the tree (point query from the root)
@@ -258,14 +308,27 @@ hipError_t launch_box_positions(const uint64_t *descriptors, uint64_t n_desc, ui
 // Builds boxes[8 * n_desc] (and aux[2^(3 lc)] when lc >= 1) on `stream`.  `pos_tmp` = n_desc uint64 of scratch.  n <= 19.
 hipError_t launch_box_build(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, int lc, uint64_t *pos_tmp,
                             uint32_t *boxes, uint32_t *aux, hipStream_t stream) {
+    const bool timing = getenv("VRC_BOX_TIMING") != nullptr;      // (diagnostics: seconds per phase on stderr)
+    auto tick = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(stream);
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vrc boxes] %s: %.4f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    };
+    if (timing) (void)hipStreamSynchronize(stream);
+    auto t0 = std::chrono::steady_clock::now();
     hipError_t e = launch_box_positions(descriptors, n_desc, root_index, n, pos_tmp, stream);
     if (e != hipSuccess) return e;
+    tick("positions", t0);
     const unsigned tb = 256;
     const uint64_t threads = n_desc * 8;
     hipLaunchKernelGGL(box_grow_kernel, dim3((unsigned)((threads + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, n_desc, root_index, n, pos_tmp, boxes);
+    tick("grow", t0);
     if (aux && lc >= 1) {
         const uint64_t cells = 1ULL << (3 * lc);
         hipLaunchKernelGGL(box_aux_kernel, dim3((unsigned)((cells + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, root_index, n, lc, boxes, aux);
+        tick("table words", t0);
     }
     return hipGetLastError();
 }

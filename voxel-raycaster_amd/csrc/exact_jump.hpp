@@ -443,7 +443,9 @@ VRC_HD JumpAxis jump_axis(float t, float d, int32_t n) {
     // conditionals the compiler made three exec-masked branches per axis out of them)
     const uint32_t mant = (uint32_t)a.tb & 0x7fffffu, steps = reg ? (uint32_t)(n - 1) : 0u, uinc = reg ? (uint32_t)a.inc : 64u;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t lo = __umul24(steps, uinc), hi = __umulhi(steps, uinc);
+    // (a full 32-bit low word, not __umul24: a countdown may reach 2^24 -- the top-level node of a depth-24 tree widened over a
+    // sibling, an empty box across a 2^19 map -- and a truncated low word under a zero high word would pass the test below)
+    const uint32_t lo = steps * uinc, hi = __umulhi(steps, uinc);
 #else
     const uint64_t p64 = (uint64_t)steps * uinc;
     const uint32_t lo = (uint32_t)p64, hi = (uint32_t)(p64 >> 32);

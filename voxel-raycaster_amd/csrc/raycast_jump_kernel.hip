@@ -27,21 +27,8 @@ __device__ __forceinline__ uint64_t jump_make_entry(const uint64_t *__restrict__
 }
 enum JumpLane { jStep = 0, jShade = 1, jDone = 2, jRelight = 3, jDescend = 4, jTable = 5 };
 
-// index of cell (cx, cy, cz) of the coarse table with 2^lc cells per axis: bricks of (2^kCoarseBrickLog2)^3 cells are contiguous,
-// bricks in x-fastest order -- the rays of a tile land in a patch of neighbouring cells, whatever plane that patch lies in
-// (measured, headline frame, table levels 8 / 9 / 10: plain x-fastest order 0.639 / 0.581 / 0.555 ms, bricks of 2^3, 4^3, 8^3 cells
-// 0.666 / 0.602 / 0.563-0.573: the index arithmetic costs more than the locality gives -- the default is no bricks)
-#ifndef VRC_COARSE_BRICK
-#define VRC_COARSE_BRICK 0
-#endif
-constexpr int kCoarseBrickLog2 = VRC_COARSE_BRICK;
-__device__ __forceinline__ uint64_t coarse_index(unsigned cx, unsigned cy, unsigned cz, int lc) {
-    constexpr unsigned k = kCoarseBrickLog2, m = (1u << k) - 1u;
-    if (k == 0 || lc < (int)k) return cx | (cy << lc) | (cz << (2 * lc));   // (32 bits: lc <= 10, vrc_api.cpp)
-    const int lb = lc - (int)k;                            // bricks per axis = 2^lb
-    const uint64_t brick = (uint64_t)(cx >> k) | ((uint64_t)(cy >> k) << lb) | ((uint64_t)(cz >> k) << (2 * lb));
-    return (brick << (3 * k)) | (cx & m) | ((cy & m) << k) | ((cz & m) << (2 * k));
-}
+// (coarse_index(): vrc_params.h -- measured, headline frame, table levels 8 / 9 / 10: plain x-fastest order 0.639 / 0.581 / 0.555 ms,
+// bricks of 2^3, 4^3, 8^3 cells 0.666 / 0.602 / 0.563-0.573)
 }  // namespace
 
 // Coarse table (round 4): one thread per cell walks the canonical descent from the root toward the cell and stores the

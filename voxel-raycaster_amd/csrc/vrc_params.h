@@ -58,6 +58,23 @@ constexpr int kMaxLevels = 24;        // descriptor levels the LDS stack can hol
 // never finer than cells of 4 voxels (the bottom two levels are always descriptors)
 constexpr int kCoarseMaxLog2 = 9;
 constexpr int kCoarseLevelShift = 59; // entry bits 59-63: level; child indices must stay below 2^43
+// index of cell (cx, cy, cz) of the coarse table (and of the boxes' parallel word) with 2^lc cells per axis: x fastest; with
+// -DVRC_COARSE_BRICK=k bricks of (2^k)^3 cells are contiguous (an experiment of round 4: the index arithmetic costs more than the
+// locality gives, so the default is no bricks).  ONE definition for the builders and every kernel that reads the table.
+#ifndef VRC_COARSE_BRICK
+#define VRC_COARSE_BRICK 0
+#endif
+constexpr int kCoarseBrickLog2 = VRC_COARSE_BRICK;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint64_t coarse_index(unsigned cx, unsigned cy, unsigned cz, int lc) {
+    constexpr unsigned k = kCoarseBrickLog2, m = (1u << k) - 1u;
+    if (k == 0 || lc < (int)k) return cx | (cy << lc) | (cz << (2 * lc));   // (32 bits: lc <= 10, vrc_api.cpp)
+    const int lb = lc - (int)k;                            // bricks per axis = 2^lb
+    const uint64_t brick = (uint64_t)(cx >> k) | ((uint64_t)(cy >> k) << lb) | ((uint64_t)(cz >> k) << (2 * lb));
+    return (brick << (3 * k)) | (cx & m) | ((cy & m) << k) | ((cz & m) << (2 * k));
+}
 // the table level for a tree of depth n (0: no table)
 constexpr int coarse_level_for_depth(int n) { return n >= 5 ? (n - 2 < kCoarseMaxLog2 ? n - 2 : kCoarseMaxLog2) : 0; }
 
