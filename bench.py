@@ -46,7 +46,8 @@ PREWARM_FRAMES = 40     # untimed frames rendered during set-up so that the GPU 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 # VALU issue peak: 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles per SIMD, 2.4 GHz (MI355X_MICROARCH.md)
 VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
-KERNEL_SOURCES = ("raycast_kernel.hip", "raycast_jump_kernel.hip", "raycast_common.hpp", "safe_run.hpp", "exact_jump.hpp", "vrc_params.h")
+KERNEL_SOURCES = ("raycast_kernel.hip", "raycast_jump_kernel.hip", "raycast_common.hpp", "safe_run.hpp", "exact_jump.hpp", "vrc_params.h",
+                  "empty_boxes.hip")      # (the boxes decide what the exact kernel reads: a changed builder orphans the traffic figure too)
 
 
 def kernel_source_hash() -> str:
@@ -60,6 +61,14 @@ def kernel_source_hash() -> str:
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         text = "\n".join(l for l in (re.sub(r"//.*$", "", ln).rstrip() for ln in text.splitlines()) if l)
         h.update(text.encode())
+    # ... and what the sources were compiled with: the flags of __graft_entry__.build() and the ROCm release (a file, not a
+    # spawned `hipcc --version`: this runs inside GPU-initialised and profiled processes)
+    import __graft_entry__ as graft
+    h.update(" ".join(f for f in graft.HIP_FLAGS if not f.startswith("-I")).encode())
+    try:
+        h.update(open("/opt/rocm/.info/version").read().strip().encode())
+    except OSError:
+        h.update(b"rocm-unknown")
     return h.hexdigest()[:16]
 
 
