@@ -25,8 +25,10 @@ def measure(c, name, extra):
         n, ms = c.timing()
         ctr = c.counters()
         rays = ctr["primary_rays"] + ctr["shadow_rays"]
+        m = c.memory_usage2()
         row = dict(config=name, mode="exact" if mode == 0 else "B (node-exit jumps)", kernel_ms=round(ms / n, 3),
-                   Mrays_s=round(rays / (ms / n) / 1e3, 1), rays=rays, steps=ctr["steps"], descriptor_reads=ctr["descriptor_reads"], **extra)
+                   Mrays_s=round(rays / (ms / n) / 1e3, 1), rays=rays, steps=ctr["steps"], descriptor_reads=ctr["descriptor_reads"],
+                   empty_boxes=m["empty_boxes"], box_build_seconds=round(m["box_build_seconds"], 3), box_MB=round(m["box_bytes"] / 1e6), **extra)
         print(json.dumps(row), flush=True)
         out.append(row)
     return out
