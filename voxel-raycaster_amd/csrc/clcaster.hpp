@@ -88,6 +88,9 @@ public:
         while ((1u << depth) < m.dimensions) depth++;
         return (1u << depth) == m.dimensions && ok(vrc_build_dense_grid(h_, depth, nullptr, VRC_BUILD_ATTACHMENTS, 0, nullptr));
     }
+    // extension: the tree another CLCaster on the same GPU already holds (two viewports of one Map, two frames in flight):
+    // adopted, not uploaded again -- one descriptor array, one coarse table, one set of empty boxes between the two
+    bool assign_octree_from(CLCaster &other) { return ok(vrc_assign_octree_from(h_, other.h_)); }
     bool release_octree() { return ok(vrc_release_octree(h_)); }                                          // :119-131
     bool assign_camera(const Camera *camera) {                                                             // :133-143
         return ok(vrc_assign_camera(h_, camera->get_direction_pointer(), camera->get_position_pointer()));
