@@ -28,6 +28,21 @@ int main(void) {
         if (vrc_create(0, &h) != VRC_OK || !h) return 6;
         if (vrc_validate(h) != VRC_ERR_NOT_READY) return 7;
         if (strstr(vrc_last_error(h), "camera") == NULL) return 8;
+        {   /* the size-versioned memory report: a caller that knows fewer fields than the library gets only what its struct holds */
+            vrc_memory2 m;
+            unsigned char guard[sizeof(vrc_memory2) + 8];
+            vrc_caster *h2 = NULL;
+            memset(&m, 0xee, sizeof(m));
+            m.struct_size = (uint32_t)sizeof(m);
+            if (vrc_memory_usage2(h, 0, &m) != VRC_OK || m.struct_size != sizeof(m) || m.tree_holders != 0 || m.box_bytes != 0) return 10;
+            memset(guard, 0xee, sizeof(guard));
+            ((vrc_memory2 *)guard)->struct_size = 24;                  /* an "older header": 24 bytes */
+            if (vrc_memory_usage2(h, 0, (vrc_memory2 *)guard) != VRC_OK || guard[24] != 0xee || guard[sizeof(guard) - 1] != 0xee) return 11;
+            /* a tree can only be adopted from a handle that has one */
+            if (vrc_create(0, &h2) != VRC_OK) return 12;
+            if (vrc_assign_octree_from(h2, h) != VRC_ERR_NOT_READY || vrc_assign_octree_from(h, h) != VRC_ERR_INVALID_ARGUMENT) return 13;
+            vrc_destroy(h2);
+        }
         vrc_destroy(h);
         printf("c-abi ok (gpu present)\n");
     } else {

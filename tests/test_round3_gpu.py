@@ -44,8 +44,8 @@ def test_soak_slice_exact_jumps_on_small_frames_of_deep_scenes():
     iteration counts off by one) of device-built depth-12 / 14 / 16 terrains, random poses, 1-4 lights, step caps and
     jump thresholds -- image, hit records and every counter equal to the same frame stepped voxel by voxel."""
     import soak_jumps_gpu
-    bad, frames, steps = soak_jumps_gpu.run(budget=15.0, seed=20261002, depths=(12, 14, 16))
-    assert frames >= 200 and steps > 1e10
+    bad, frames, steps = soak_jumps_gpu.run(budget=15.0, seed=20261002, depths=(10, 12, 14, 16))   # (depths 10 and 12: through the empty boxes)
+    assert frames >= 150 and steps > 1e10
     assert bad == 0
 
 
