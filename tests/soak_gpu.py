@@ -24,6 +24,9 @@ def run(budget=300.0, seed=1, depth=12, sc=None):
     sc = sc or bench.build_scene(depth)
     dim, w, h = sc["dim"], 512, 288
     t0, poses, rows, bad, by_mode = time.time(), 0, 0, 0, [0, 0]
+    # the tree, its coarse table and its boxes are uploaded / built ONCE and kept by this holder; every pose's caster adopts them
+    holder = vrc.CLCaster()
+    assert holder.init(0) and holder.assign_octree(sc["octree"]), holder.last_error()
     while time.time() - t0 < budget:
         cam_pos = tuple(float(v) for v in (rng.random(3) * (dim * 1.2) - 0.1 * dim))
         if rng.random() < 0.5:                       # mostly above the terrain
@@ -42,12 +45,12 @@ def run(budget=300.0, seed=1, depth=12, sc=None):
             cd, cp = np.array(cam_dir, dtype=np.float32), np.array(cam_pos, dtype=np.float32)
             ok = (c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c.add_to_settings_buffer("using_octree", "OCTENABLED", 0)
                   and c.add_to_settings_buffer("max_distance", "MAX_DISTANCE", md) and c.add_to_settings_buffer("light_count", "LIGHT_COUNT", nl)
-                  and c.assign_octree(sc["octree"]) and c.assign_camera(cd, cp) and c.create_viewport(w, h) and c.assign_lights(lights)
+                  and c.assign_octree_from(holder) and c.assign_camera(cd, cp) and c.create_viewport(w, h) and c.assign_lights(lights)
                   and c.create_texture_atlas(sc["atlas"], (16, 16)) and c.validate())
             assert ok, c.last_error()
             c._li = lights
         else:
-            c = make_caster(sc["octree"], dim, 0, cam_dir, cam_pos, lights, sc["atlas"], w, h, md, light_count=nl)
+            c = make_caster(sc["octree"], dim, 0, cam_dir, cam_pos, lights, sc["atlas"], w, h, md, light_count=nl, tree_from=holder)
         assert c.add_to_settings_buffer("stepping_mode", "STEPPING_MODE", mode)
         assert c.compute(), c.last_error()
         img, hits, rgba = c.read_image(), c.read_hits(), c.read_image_rgba8()

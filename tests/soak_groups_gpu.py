@@ -18,12 +18,13 @@ import bench  # noqa: E402
 import voxel_raycaster_amd as vrc  # noqa: E402
 
 
-def setup(c, sc, tree, w, h, cam, li, settings):
+def setup(c, sc, tree, w, h, cam, li, settings, holder=None):
+    """holder: a caster that keeps this tree (with its coarse table and boxes) on the GPU; adopted instead of uploaded again"""
     dim = sc["dim"]
     ok = (c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim) and c.add_to_settings_buffer("using_octree", "OCTENABLED", 0))
     for k, v in settings.items():
         ok = ok and c.add_to_settings_buffer(k, k.upper(), v)
-    ok = (ok and c.assign_octree(tree) and c.assign_camera(*cam) and c.create_viewport(w, h) and c.assign_lights(li)
+    ok = (ok and (c.assign_octree_from(holder) if holder is not None else c.assign_octree(tree)) and c.assign_camera(*cam) and c.create_viewport(w, h) and c.assign_lights(li)
           and c.create_texture_atlas(sc["atlas"], (16, 16)) and c.validate())
     assert ok, c.last_error()
 
@@ -39,10 +40,16 @@ def run(budget=300.0, seed=1, depths=(8, 10, 12)):
             sc = bench.build_scene(depth)
             plain = sc["octree"]
             mats = vrc.Octree(plain.descriptor_buffer, plain.root_index, plain.dim).attach_materials_procedural(depth, seed=1, mirror_period=64)
-            scenes[depth] = (sc, plain, mats)
-        sc, plain, mats = scenes[depth]
+            holders = []
+            for t in (plain, mats):                  # one resident copy of each tree (array, coarse table, boxes) per scene
+                hc = vrc.CLCaster()
+                assert hc.init(0) and hc.assign_octree(t), hc.last_error()
+                holders.append(hc)
+            scenes[depth] = (sc, plain, mats, holders)
+        sc, plain, mats, holders = scenes[depth]
         dim = sc["dim"]
-        tree = mats if rng.random() < 0.3 else plain
+        use_mats = bool(rng.random() < 0.3)
+        tree, holder = (mats, holders[1]) if use_mats else (plain, holders[0])
         w, h = int(rng.integers(1, 700)), int(rng.integers(1, 400))
         if rng.random() < 0.2:
             w, h = int(rng.choice([1, 2, 63, 64, 65, 1920])), int(rng.choice([1, 2, 7, 8, 9, 1080]))
@@ -60,13 +67,13 @@ def run(budget=300.0, seed=1, depths=(8, 10, 12)):
             settings["jump_min_run"] = int(rng.choice([16, 64, 96, 1 << 24]))
         one = vrc.CLCaster()
         assert one.init(0)
-        setup(one, sc, tree, w, h, cam, li, settings)
+        setup(one, sc, tree, w, h, cam, li, settings, holder)
         assert one.compute(), one.last_error()
         ref = (one.read_image(), one.read_hits(), one.read_image_rgba8(), one.counters())
         g = vrc.CLCaster()
         own = bool(rng.random() < 0.3)
         assert g.init_group([0] * ranks, band_rows=band, own_copies=own) and g.group_size() == ranks, g.last_error()
-        setup(g, sc, tree, w, h, cam, li, settings)
+        setup(g, sc, tree, w, h, cam, li, settings, None if (own or rng.random() < 0.3) else holder)   # (own copies: an upload of its own, fanned out rank by rank)
         assert g.compute(), g.last_error()
         img = np.zeros_like(ref[0])
         pinned = bool(rng.random() < 0.3)

@@ -22,7 +22,7 @@ RTOL = 1e-5  # BASELINE.json north_star tolerance for RGB floats
 
 
 def make_caster(octree, dim, using_octree, cam_dir, cam_pos, lights, atlas, w, h, max_distance, grid=None,
-                shadow_rays=1, light_count=None, empty_boxes=None):
+                shadow_rays=1, light_count=None, empty_boxes=None, tree_from=None):
     c = vrc.CLCaster()
     assert c.init(0), "vrc_create failed: is this a GPU box?"
     assert c.add_to_settings_buffer("octree_dimensions", "OCTDIM", dim)          # Application.cpp:35
@@ -33,7 +33,9 @@ def make_caster(octree, dim, using_octree, cam_dir, cam_pos, lights, atlas, w, h
         assert c.add_to_settings_buffer("light_count", "LIGHT_COUNT", light_count)
     if empty_boxes is not None:                                                  # None: the library's rule (on where the tree has a coarse table)
         assert c.add_to_settings_buffer("empty_boxes", "EMPTY_BOXES", empty_boxes)
-    assert c.assign_octree(octree)
+    # tree_from: a caster on this GPU that already holds this very tree -- adopted (vrc_assign_octree_from: one array, one coarse
+    # table, one set of boxes), not uploaded and annotated again
+    assert c.assign_octree_from(tree_from) if tree_from is not None else c.assign_octree(octree), c.last_error()
     if grid is not None:
         assert c.assign_map(grid, (dim, dim, dim))
     cd, cp = np.array(cam_dir, dtype=np.float32), np.array(cam_pos, dtype=np.float32)

@@ -165,3 +165,34 @@ def test_optional_structures_fail_soft(atlas):
     assert c.overwrite_setting("coarse_log2", -1)
     got = _frame(c)
     assert c.used_empty_boxes() and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+
+
+def test_shared_tree_materials_follow_either_handle(atlas):
+    """Materials belong to the TREE (vrc_assign_octree_from's contract): assigned through one holder they are rendered by the
+    other from its next frame on -- mirrors and pass-through voxels appear -- and both frames equal the oracle's."""
+    from test_oracle_cpu import _with_pass_through
+    s = _with_pass_through(scenes.mirror_wall())
+    dim, w, h = s["dim"], 128, 96
+    plain = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
+    with_mat = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000).attach_materials_from_grid(s["grid"])
+    a = make_caster(plain, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, 3 * dim)
+    b = make_caster(plain, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, 3 * dim, tree_from=a)
+    assert b.memory_usage2()["tree_holders"] == 2
+
+    def oracle(tree):
+        return orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=a._li, atlas=atlas, tile_dim=(16, 16),
+                           descriptors=tree.descriptor_buffer, root_index=tree.root_index, octree_dim=dim, using_octree=0, max_distance=3 * dim,
+                           attachment_lookup=tree.attachment_lookup, attachments=tree.attachment_buffer)
+
+    assert b.compute(), b.last_error()
+    assert_same(b.read_image(), b.read_hits(), b.counters(), *oracle(plain))
+    assert a.assign_octree_attachments(with_mat) and a.validate() and b.validate()
+    for c in (b, a):
+        assert c.compute(), c.last_error()
+        oimg, ohits, octr = oracle(with_mat)
+        assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
+    assert (ohits[..., 3] == 6).sum() > 0
+    # ... and taken away again through the OTHER holder
+    assert vrc.lib.vrc_assign_octree_attachments(b._h, None, 0, None, 0) == 0 and a.validate() and b.validate()
+    assert a.compute(), a.last_error()
+    assert_same(a.read_image(), a.read_hits(), a.counters(), *oracle(plain))

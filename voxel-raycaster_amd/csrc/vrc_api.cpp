@@ -69,6 +69,9 @@ struct vrc_tree {
     bool coarse_gave_up = false, boxes_gave_up = false;   // an allocation failed: the frames go on without (not retried every frame)
     std::string note;                                     // why
     ~vrc_tree() {
+        // (the caller's current device is left as it was: a group that lets go of its peers' trees goes on allocating on rank 0's GPU)
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
         (void)hipSetDevice(device);
         if (d_coarse) (void)hipFree(d_coarse);
         if (d_boxes) (void)hipFree(d_boxes);
@@ -76,6 +79,8 @@ struct vrc_tree {
         if (d_desc) (void)hipFree(d_desc);
         if (d_attach_lookup) (void)hipFree(d_attach_lookup);
         if (d_attach) (void)hipFree(d_attach);
+        if (cur >= 0) (void)hipSetDevice(cur);
+        (void)hipGetLastError();
     }
 };
 
@@ -980,6 +985,7 @@ namespace {
 int compute_async_one(vrc_caster *h) {
     if (!h->validated) return fail(h, VRC_ERR_NOT_READY, "compute: validate() has not succeeded");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->tree) mirror_tree(h);           // (a handle that shares the tree may have given it new materials since the last frame)
 
     // settings stay live after validate() (CLCaster::overwrite_setting needs no recompile, CLCaster.cpp:1087-1109), so
     // the structural ones are checked again here: a bad value is an error return, never a device fault
@@ -1158,9 +1164,9 @@ int compute_async_one(vrc_caster *h) {
                 }
             }
             if (t->d_boxes) { p.boxes = t->d_boxes; p.box_aux = t->d_box_aux; }
-        } else if (t->d_boxes && want_boxes == 0 && h->tree.use_count() == 1) {
-            release(t->d_boxes); release(t->d_box_aux); t->box_log2 = 0;   // the setting went to "never" and nobody else renders this tree
         }
+        // (a handle that switches the boxes off keeps them: they belong to the tree, go with it, and a host that toggles the setting
+        // between frames -- tests/soak_jumps_gpu.py does -- must not pay the build again and again)
     }
     // exact closed-form jumps: on from depth 12; the threshold depends on where the Euclid tables live (LDS when stack + tables
     // fit at full occupancy: depth 12)
