@@ -235,6 +235,12 @@ int vrc_memory_usage2(vrc_caster *h, int32_t rank, vrc_memory2 *out);
  * 0.  build_seconds: device time of the boxes' construction.  Any out pointer may be NULL.                              */
 int vrc_empty_boxes_check(vrc_caster *h, uint64_t samples, uint64_t seed, uint64_t *boxes_sampled, uint64_t *solid_voxels,
                           double *build_seconds);
+/* The box words themselves: out[8 * i + k] belongs to child slot k = x | y<<1 | z<<2 of descriptor first_descriptor + i and
+ * means something where that child is empty (not valid): six 5-bit extents, bits 0-4 -x, 5-9 -y, 10-14 -z, 15-19 +x, 20-24 +y,
+ * 25-29 +z, in units of the child's own size; code c stands for c (c < 4), (4 | c & 3) << (c / 4 - 1) otherwise.  The box is
+ * the child's cube widened by those extents, clamped to the map.  (tests/test_round5_gpu.py checks every voxel of every box of
+ * small trees against the dense grid on the host.)                                                                         */
+int vrc_read_empty_boxes(vrc_caster *h, uint64_t first_descriptor, uint64_t count, uint32_t *out);
 
 /* ---- output ------------------------------------------------------------ */
 

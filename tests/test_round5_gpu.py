@@ -196,3 +196,45 @@ def test_shared_tree_materials_follow_either_handle(atlas):
     assert vrc.lib.vrc_assign_octree_attachments(b._h, None, 0, None, 0) == 0 and a.validate() and b.validate()
     assert a.compute(), a.last_error()
     assert_same(a.read_image(), a.read_hits(), a.counters(), *oracle(plain))
+
+
+@pytest.mark.parametrize("make", [scenes.random_sparse, scenes.floor_pillars, scenes.open_sky, scenes.terrain256],
+                         ids=["random_sparse64", "floor_pillars32", "open_sky32", "terrain256"])
+def test_every_voxel_of_every_box_is_empty_on_the_host(make, atlas):
+    """The box words read back (vrc_read_empty_boxes) and checked EXHAUSTIVELY on the host, with nothing of the device's own
+    machinery: an independent walk of the descriptor array gives every empty child slot its cube, the word gives the box, and
+    the dense grid the tree was generated from must hold no solid voxel anywhere inside it.  Also: every box contains its own
+    node (extents are non-negative by construction) and boxes do grow (the structure is not vacuous)."""
+    import treetools
+    s = make()
+    dim = s["dim"]
+    grid = np.asarray(s["grid"]).reshape(dim, dim, dim) != 0          # [z, y, x]
+    o = vrc.Octree.Generate(s["grid"], dim, buffer_size=0 if dim > 64 else 100000)
+    c = make_caster(o, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, 64, 48, 3 * dim, empty_boxes=1)
+    assert c.compute(), c.last_error()
+    assert c.used_empty_boxes()
+    words = c.read_empty_boxes()
+    assert words.shape == (o.descriptor_buffer.size, 8)
+    # solid voxels in any box in O(1): a summed-volume table of the dense grid, S[z, y, x] = solids in [0, z) x [0, y) x [0, x)
+    S = np.zeros((dim + 1, dim + 1, dim + 1), dtype=np.int64)
+    S[1:, 1:, 1:] = grid.astype(np.int64).cumsum(0).cumsum(1).cumsum(2)
+
+    def solids(x0, y0, z0, x1, y1, z1):
+        return int(S[z1, y1, x1] - S[z0, y1, x1] - S[z1, y0, x1] - S[z1, y1, x0] + S[z0, y0, x1] + S[z0, y1, x0] + S[z1, y0, x0] - S[z0, y0, x0])
+
+    assert solids(0, 0, 0, dim, dim, dim) == int(grid.sum()) > 0
+    n_boxes = grown = 0
+    volume = node_volume = 0
+    for index, k, (x, y, z), size in treetools.empty_children(o.descriptor_buffer, o.root_index, dim):
+        w = int(words[index, k])
+        ext = [treetools.box_decode((w >> (5 * j)) & 31) * size for j in range(6)]      # -x -y -z +x +y +z
+        x0, y0, z0 = max(x - ext[0], 0), max(y - ext[1], 0), max(z - ext[2], 0)
+        x1, y1, z1 = min(x + size + ext[3], dim), min(y + size + ext[4], dim), min(z + size + ext[5], dim)
+        assert solids(x0, y0, z0, x1, y1, z1) == 0, f"descriptor {index} slot {k}: the box {(x0, y0, z0)}..{(x1, y1, z1)} of the {size}^3 node at {(x, y, z)} holds a solid voxel"
+        n_boxes += 1
+        grown += any(ext)
+        volume += (x1 - x0) * (y1 - y0) * (z1 - z0)
+        node_volume += size ** 3
+    assert n_boxes > 20 and grown > n_boxes // 4
+    print(f"\n{s['name']}: {n_boxes} empty child slots, {grown} of them widened; mean box volume {volume / n_boxes:.0f} voxels "
+          f"({volume / node_volume:.1f} x the nodes')")

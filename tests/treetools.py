@@ -66,3 +66,33 @@ def sparse_octree(voxels, depth: int):
             out.append(0)
         out[index] = (first - index) | (valid << 16) | ((~valid & 0xff) << 24)
     return np.array(out, dtype=np.uint64), 0
+
+
+def box_decode(c):
+    """Extent code of the empty boxes (include/vrc.h vrc_read_empty_boxes): c (c < 4), (4 | c & 3) << (c / 4 - 1) otherwise."""
+    c = int(c)
+    return c if c < 4 else (4 | (c & 3)) << ((c >> 2) - 1)
+
+
+def empty_children(desc: np.ndarray, root: int, dim: int):
+    """Every EMPTY child slot of every descriptor the root reaches: yields (descriptor index, slot, (x, y, z) of the child's
+    cube, its size) -- an independent walk of the array on the host (format of include/map/Octree.h:89-94)."""
+    d = [int(v) for v in desc]
+    stack = [(int(root), 0, 0, 0, dim)]
+    while stack:
+        index, x, y, z, size = stack.pop()
+        v = d[index]
+        valid, leaf = (v >> 16) & 0xff, (v >> 24) & 0xff
+        half = size // 2
+        at = index + (v & 0x7fff)
+        if v & 0x8000:
+            at = d[at]
+        rank = 0
+        for k in range(8):
+            cx, cy, cz = x + (half if k & 1 else 0), y + (half if k & 2 else 0), z + (half if k & 4 else 0)
+            if not (valid >> k & 1):
+                yield index, k, (cx, cy, cz), half
+                continue
+            if half > 1 and not (leaf >> k & 1):
+                stack.append((at + rank, cx, cy, cz, half))
+            rank += 1

@@ -146,6 +146,7 @@ SIGNATURES = {
     "vrc_memory_usage": (C.c_int, [_H, C.c_int32, C.POINTER(Memory)]),
     "vrc_empty_boxes_check": (C.c_int, [_H, C.c_uint64, C.c_uint64, _u64p, _u64p, C.POINTER(C.c_double)]),
     "vrc_assign_octree_from": (C.c_int, [_H, _H]),
+    "vrc_read_empty_boxes": (C.c_int, [_H, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),
     "vrc_memory_usage2": (C.c_int, [_H, C.c_int32, C.POINTER(Memory2)]),
     "vrc_scene_shell_terrain_ex": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(_u64p), _u64p, _u64p, _i32p]),
     "vrc_scene_shell_column": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _i32p, _i32p]),
@@ -442,6 +443,18 @@ class CLCaster:
         if not self._ok(lib.vrc_memory_usage(self._h, rank, C.byref(m))):
             raise VrcError(self.last_error())
         return m.as_dict()
+
+    def read_empty_boxes(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """vrc_read_empty_boxes: uint32[count, 8] box words of the descriptors first .. first + count (all of them by default)."""
+        if count is None:
+            n = C.c_uint64()
+            if not self._ok(lib.vrc_octree_size(self._h, C.byref(n), None)):
+                raise VrcError(self.last_error())
+            count = int(n.value) - first
+        out = np.zeros((count, 8), dtype=np.uint32)
+        if not self._ok(lib.vrc_read_empty_boxes(self._h, first, count, _ptr(out, C.POINTER(C.c_uint32)))):
+            raise VrcError(self.last_error())
+        return out
 
     def memory_usage2(self, rank: int = 0) -> dict:
         """vrc_memory_usage2: the size-versioned form, with what is held per TREE (coarse table, empty boxes, holders)."""

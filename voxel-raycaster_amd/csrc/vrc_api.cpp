@@ -1340,6 +1340,17 @@ int vrc_empty_boxes_check(vrc_caster *h, uint64_t samples, uint64_t seed, uint64
     return VRC_OK;
 }
 
+// read-back of the box words (tests: every voxel of every box of a small tree against its dense grid, on the host)
+int vrc_read_empty_boxes(vrc_caster *h, uint64_t first_descriptor, uint64_t count, uint32_t *out) {
+    if (!h || !out) return VRC_ERR_INVALID_ARGUMENT;
+    vrc_tree *t = h->tree.get();
+    if (!t || !t->d_boxes) return fail(h, VRC_ERR_NOT_READY, "read_empty_boxes: no boxes (setting empty_boxes, or no frame computed yet)");
+    if (first_descriptor > t->n_desc || count > t->n_desc - first_descriptor) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_empty_boxes: range past the array");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(out, t->d_boxes + 8 * first_descriptor, sizeof(uint32_t) * 8 * count, hipMemcpyDeviceToHost));
+    return VRC_OK;
+}
+
 // vrc_memory_usage with a size-versioned struct (the caller says how large ITS struct is; never more than that is written)
 int vrc_memory_usage2(vrc_caster *h, int32_t rank, vrc_memory2 *out) {
     if (!h || !out || rank < 0 || rank > (int32_t)h->peers.size() || out->struct_size < sizeof(uint32_t)) return VRC_ERR_INVALID_ARGUMENT;
