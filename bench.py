@@ -217,7 +217,7 @@ def canonical_counters(c) -> dict:
 def kernel_instance(c, sc, lights) -> str:
     """The template instance vrc_api.cpp / raycast_kernel.hip launch_raycast picks for this caster's default settings."""
     m = c.memory_usage2()
-    jump = sc["depth"] >= 12
+    jump = sc["depth"] >= (11 if m["empty_boxes"] else 12)
     flags = [jump, lights > 1, True, jump, m["coarse_log2"] > 0, bool(m["empty_boxes"])]
     return "raycast_svo_kernel<" + ", ".join("true" if f else "false" for f in flags) + ">  (kJump, kMulti, kTuned, kLdsTab, kCoarse, kBox)"
 

@@ -18,6 +18,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--check", type=int, default=1 << 22)
 ap.add_argument("--shadow", type=int, default=1)
 ap.add_argument("--set", action="append", default=[])
+ap.add_argument("--modes", type=int, nargs="*", default=[0, 1], help="empty_boxes values to compare; the first is the reference frame (0: none, 1: full, 2: table cells only, -1: the default rule)")
 a = ap.parse_args()
 
 
@@ -36,7 +37,7 @@ for depth in a.depths:
     for lights in a.lights:
         out = {"depth": depth, "lights": lights, "frame": f"{a.width}x{a.height}"}
         frames = {}
-        for boxes in (0, 1):
+        for boxes in a.modes:
             c = bench.make_caster(sc, a.width, a.height, 0, light_count=lights, hit_records=1, shadow_rays=a.shadow)
             assert c.add_to_settings_buffer("empty_boxes", "EMPTY_BOXES", boxes)
             for kv in a.set:
@@ -49,15 +50,19 @@ for depth in a.depths:
             assert c.overwrite_setting("hit_records", 0)
             out[f"ms_boxes{boxes}"] = round(timed(c, a.frames), 4)
             out[f"desc_reads_boxes{boxes}"] = ctr["descriptor_reads"]
-            if boxes:
-                out["check"] = c.empty_boxes_check(a.check, 7)
-                out["memory"] = c.memory_usage()
+            if c.used_empty_boxes():
+                out[f"check_boxes{boxes}"] = c.empty_boxes_check(a.check, 7)
+                m = c.memory_usage2()
+                out[f"box_MB_boxes{boxes}"] = round(m["box_bytes"] / 1e6)
             del c
-        (i0, h0, c0), (i1, h1, c1) = frames[0], frames[1]
-        h0 = h0.reshape(-1, 8); h1 = h1.reshape(-1, 8)
-        out["image_bits_equal"] = bool(np.array_equal(i0.view(np.uint32), i1.view(np.uint32)))
-        out["hits_equal_but_desc"] = bool(np.array_equal(h0[:, :7], h1[:, :7]))
-        out["differing_pixels"] = int(np.count_nonzero(np.any(i0.reshape(-1, 4).view(np.uint32) != i1.reshape(-1, 4).view(np.uint32), axis=1)))
-        out["differing_hit_rows"] = int(np.count_nonzero(np.any(h0[:, :7] != h1[:, :7], axis=1)))
-        out["counters_equal_but_desc"] = all(c0[k] == c1[k] for k in c0 if k != "descriptor_reads")
+        i0, h0, c0 = frames[a.modes[0]]
+        h0 = h0.reshape(-1, 8)
+        for boxes in a.modes[1:]:
+            i1, h1, c1 = frames[boxes]
+            h1 = h1.reshape(-1, 8)
+            out[f"same_as_first_boxes{boxes}"] = dict(
+                image_bits=bool(np.array_equal(i0.view(np.uint32), i1.view(np.uint32))), hits_but_reads=bool(np.array_equal(h0[:, :7], h1[:, :7])),
+                differing_pixels=int(np.count_nonzero(np.any(i0.reshape(-1, 4).view(np.uint32) != i1.reshape(-1, 4).view(np.uint32), axis=1))),
+                differing_hit_rows=int(np.count_nonzero(np.any(h0[:, :7] != h1[:, :7], axis=1))),
+                counters_but_reads=all(c0[k] == c1[k] for k in c0 if k not in ("descriptor_reads", "canonical_reads")))
         print(json.dumps(out), flush=True)

@@ -34,7 +34,8 @@ def hist(c, name, sets=()):
     print(json.dumps({"scene": name, "sched": c.scheduler_stats(),
                       "jumps": dict(block_passes=js[0], lane_jumps=js[1], iterations_covered=js[2], left_node=js[3], capped=js[4],
                                     pair_solves=js[5], lanes_wanting=js[6], rounds=js[7]),
-                      "safe_run": dict(wave_iterations=int(buf[105]), ungated_prefix_could_cover=int(buf[104]))}), flush=True)
+                      "safe_run": dict(wave_iterations=int(buf[105]), ungated_prefix_could_cover=int(buf[104])),
+                      "empty_nodes_entered": dict(above_the_table_level=int(buf[106]), below_it=int(buf[107]))}), flush=True)
 
 
 def device_caster(depth, w=1920, h=1080, thickness=2):

@@ -145,6 +145,64 @@ __device__ bool region_is_empty(const uint64_t *__restrict__ descriptors, const 
     }
 }
 
+// The box of the empty child slot k of the descriptor at `level` whose cube starts at (nx, ny, nz): path[0 .. level] = the entries of
+// the descriptor's ancestors and its own, root first.  Returns the six 5-bit extent codes.
+__device__ uint32_t grow_box(const uint64_t *__restrict__ descriptors, const uint64_t *path, int level, int nx, int ny, int nz, int k, int n) {
+    const int b = n - level - 1, s = 1 << b, dim = 1 << n;
+    int lo[3], hi[3];
+    lo[0] = nx + ((k & 1) ? s : 0);
+    lo[1] = ny + ((k & 2) ? s : 0);
+    lo[2] = nz + ((k & 4) ? s : 0);
+    for (int a = 0; a < 3; a++) hi[a] = lo[a] + s;
+    const int org_lo[3] = {lo[0], lo[1], lo[2]}, org_hi[3] = {hi[0], hi[1], hi[2]};
+    unsigned code[6] = {0, 0, 0, 0, 0, 0};          // -x -y -z +x +y +z
+    unsigned stride[6] = {1, 1, 1, 1, 1, 1};        // code steps the side tries next: doubled while it succeeds, halved from its first failure on
+    unsigned alive = 0x3fu, doubling = 0x3fu;
+    // the sides in turn, z first (open sky above a terrain costs nothing to claim).  A side gallops: 1, 2, 4, ... code steps
+    // per turn while the slab is empty, then a binary search back from the first slab that is not -- at most ten queries a
+    // side instead of thirty-one single steps (the build of the depth-12 scene: 1.09 -> 0.63 s, depth 10: 61 -> 36 ms)
+    const int order[6] = {5, 2, 3, 0, 4, 1};
+    while (alive) {
+        for (int oi = 0; oi < 6; oi++) {
+            const int side = order[oi];
+            if (!(alive & (1u << side))) continue;
+            const int a = side % 3;
+            const bool positive = side >= 3;
+            unsigned next = code[side] + stride[side];
+            if (next > 31u && code[side] < 31u) next = 31u;
+            // the box already reaches the map's edge on this side, or the code is exhausted
+            if (next > 31u || (positive ? hi[a] >= dim : lo[a] <= 0)) { alive &= ~(1u << side); continue; }
+            const long long ext = (long long)box_decode(next) << b;     // (448 node sizes of a 2^23-voxel node do not fit an int)
+            int slo[3] = {lo[0], lo[1], lo[2]}, shi[3] = {hi[0], hi[1], hi[2]};
+            int new_edge;
+            if (positive) { const long long e = (long long)org_hi[a] + ext; new_edge = e > dim ? dim : (int)e; slo[a] = hi[a]; shi[a] = new_edge; }
+            else { const long long e = (long long)org_lo[a] - ext; new_edge = e < 0 ? 0 : (int)e; shi[a] = lo[a]; slo[a] = new_edge; }
+            if (positive ? new_edge == dim : new_edge == 0) {
+                // clipped at the map's edge: the SMALLEST code that reaches the edge is stored, so that what the kernel decodes
+                // (extent << b, in an int) never exceeds twice the map
+                const long long need = positive ? (long long)dim - org_hi[a] : (long long)org_lo[a];
+                unsigned c = code[side] + 1u;
+                while (c < next && ((long long)box_decode(c) << b) < need) c++;
+                next = c;
+            }
+            if (region_is_empty(descriptors, path, level + 1, nx, ny, nz, n, slo, shi)) {
+                code[side] = next;
+                if (positive) hi[a] = new_edge; else lo[a] = new_edge;
+                if (doubling & (1u << side)) stride[side] <<= 1;
+                else if ((stride[side] >>= 1) == 0) alive &= ~(1u << side);
+            } else if (stride[side] == 1) {
+                alive &= ~(1u << side);
+            } else {
+                stride[side] >>= 1;
+                doubling &= ~(1u << side);
+            }
+        }
+    }
+    uint32_t word = 0;
+    for (int side = 0; side < 6; side++) word |= code[side] << (5 * side);
+    return word;
+}
+
 __global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64_t n_desc, uint64_t root_index, int n,
                                 const uint64_t *__restrict__ pos, uint32_t *__restrict__ boxes) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,7 +215,6 @@ __global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64
         const unsigned valid = (unsigned)(descriptors[idx] >> 16) & 0xffu;
         if (!(valid & (1u << k))) {
             const int level = (int)(ps >> kPosLevelShift);
-            const int b = n - level - 1, s = 1 << b, dim = 1 << n;
             const int nx = (int)(ps & ((1u << kPosBits) - 1u)), ny = (int)((ps >> kPosBits) & ((1u << kPosBits) - 1u)), nz = (int)((ps >> (2 * kPosBits)) & ((1u << kPosBits) - 1u));
             // the entries of the descriptor's ancestors and its own, root first (the canonical descent toward the node)
             uint64_t path[kMaxLevels];
@@ -169,48 +226,7 @@ __global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64
                 const uint64_t child = (e >> 16) + (uint64_t)(__popc((unsigned)e & 0xffu & ((2u << i) - 1u)) - 1);
                 path[l + 1] = bx_entry(descriptors, child, descriptors[child]);
             }
-            int lo[3], hi[3];
-            lo[0] = nx + ((k & 1) ? s : 0);
-            lo[1] = ny + ((k & 2) ? s : 0);
-            lo[2] = nz + ((k & 4) ? s : 0);
-            for (int a = 0; a < 3; a++) hi[a] = lo[a] + s;
-            const int org_lo[3] = {lo[0], lo[1], lo[2]}, org_hi[3] = {hi[0], hi[1], hi[2]};
-            unsigned code[6] = {0, 0, 0, 0, 0, 0};          // -x -y -z +x +y +z
-            unsigned stride[6] = {1, 1, 1, 1, 1, 1};        // code steps the side tries next: doubled while it succeeds, halved from its first failure on
-            unsigned alive = 0x3fu, doubling = 0x3fu;
-            // the sides in turn, z first (open sky above a terrain costs nothing to claim).  A side gallops: 1, 2, 4, ... code steps
-            // per turn while the slab is empty, then a binary search back from the first slab that is not -- at most ten queries a
-            // side instead of thirty-one single steps (the build of the depth-12 scene: 1.09 -> s)
-            const int order[6] = {5, 2, 3, 0, 4, 1};
-            while (alive) {
-                for (int oi = 0; oi < 6; oi++) {
-                    const int side = order[oi];
-                    if (!(alive & (1u << side))) continue;
-                    const int a = side % 3;
-                    const bool positive = side >= 3;
-                    unsigned next = code[side] + stride[side];
-                    if (next > 31u && code[side] < 31u) next = 31u;
-                    // the box already reaches the map's edge on this side, or the code is exhausted
-                    if (next > 31u || (positive ? hi[a] >= dim : lo[a] <= 0)) { alive &= ~(1u << side); continue; }
-                    const int ext = box_decode(next) << b;
-                    int slo[3] = {lo[0], lo[1], lo[2]}, shi[3] = {hi[0], hi[1], hi[2]};
-                    int new_edge;
-                    if (positive) { new_edge = org_hi[a] + ext; if (new_edge > dim) new_edge = dim; slo[a] = hi[a]; shi[a] = new_edge; }
-                    else { new_edge = org_lo[a] - ext; if (new_edge < 0) new_edge = 0; shi[a] = lo[a]; slo[a] = new_edge; }
-                    if (region_is_empty(descriptors, path, level + 1, nx, ny, nz, n, slo, shi)) {
-                        code[side] = next;
-                        if (positive) hi[a] = new_edge; else lo[a] = new_edge;
-                        if (doubling & (1u << side)) stride[side] <<= 1;
-                        else if ((stride[side] >>= 1) == 0) alive &= ~(1u << side);
-                    } else if (stride[side] == 1) {
-                        alive &= ~(1u << side);
-                    } else {
-                        stride[side] >>= 1;
-                        doubling &= ~(1u << side);
-                    }
-                }
-            }
-            for (int side = 0; side < 6; side++) word |= code[side] << (5 * side);
+            word = grow_box(descriptors, path, level, nx, ny, nz, k, n);
         }
     }
     boxes[t] = word;
@@ -290,6 +306,53 @@ __global__ void box_check_kernel(const uint64_t *__restrict__ descriptors, uint6
     }
 }
 
+// the same self-check for the words of the table's cells (the coarse space's boxes; the only ones a very large tree has)
+__global__ void box_check_cells_kernel(const uint64_t *__restrict__ descriptors, uint64_t root_index, int n, int lc,
+                                       const uint32_t *__restrict__ aux, uint64_t samples, uint64_t seed, unsigned long long *__restrict__ result) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= samples) return;
+    const uint64_t r0 = bx_mix(seed ^ t), r1 = bx_mix(r0), r2 = bx_mix(r1);
+    const uint64_t cell = r0 & ((1ULL << (3 * lc)) - 1ULL);
+    const int sh = n - lc, dim = 1 << n;
+    const unsigned ccx = (unsigned)(cell & ((1u << lc) - 1u)), ccy = (unsigned)((cell >> lc) & ((1u << lc) - 1u)), ccz = (unsigned)(cell >> (2 * lc));
+    const int x = (int)(ccx << sh), y = (int)(ccy << sh), z = (int)(ccz << sh);
+    uint64_t cur = bx_entry(descriptors, root_index, descriptors[root_index]);
+    int b = 0;
+    for (int top = 0;; top++) {
+        if (top == lc) return;                            // the descent goes on below the table: no word for this cell
+        b = n - top - 1;
+        const int i = ((x >> b) & 1) | (((y >> b) & 1) << 1) | (((z >> b) & 1) << 2);
+        const unsigned masks = (unsigned)cur & 0xffffu, bit = 1u << i;
+        if (!(masks & bit)) break;                        // the empty node of 2^b voxels around the cell
+        if ((masks >> 8) & bit) return;
+        const uint64_t child = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
+        cur = bx_entry(descriptors, child, descriptors[child]);
+    }
+    const uint32_t w = aux[coarse_index(ccx, ccy, ccz, lc)];
+    const int nm = ~((1 << b) - 1);
+    long long lo[3] = {x & nm, y & nm, z & nm}, hi[3];
+    for (int a = 0; a < 3; a++) {
+        hi[a] = lo[a] + (1LL << b) + ((long long)box_decode((w >> (15 + 5 * a)) & 31u) << b);
+        lo[a] -= (long long)box_decode((w >> (5 * a)) & 31u) << b;
+        if (lo[a] < 0) lo[a] = 0;
+        if (hi[a] > dim) hi[a] = dim;
+    }
+    atomicAdd(&result[0], 1ULL);
+    int v[3];
+    for (int a = 0; a < 3; a++) v[a] = (int)(lo[a] + (long long)((r2 >> (20 * a)) % (uint64_t)(hi[a] - lo[a])));
+    if (r1 & 8u) { const int a = (int)((r1 >> 4) % 3u); v[a] = (int)((r1 & 64u) ? hi[a] - 1 : lo[a]); }
+    cur = bx_entry(descriptors, root_index, descriptors[root_index]);
+    for (int top = 0;; top++) {
+        const int bb = n - top - 1;
+        const int i = ((v[0] >> bb) & 1) | (((v[1] >> bb) & 1) << 1) | (((v[2] >> bb) & 1) << 2);
+        const unsigned masks = (unsigned)cur & 0xffffu, bit = 1u << i;
+        if (!(masks & bit)) return;
+        if (((masks >> 8) & bit) || bb == 0) { atomicAdd(&result[1], 1ULL); return; }
+        const uint64_t child = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
+        cur = bx_entry(descriptors, child, descriptors[child]);
+    }
+}
+
 }  // namespace
 
 // pos[n_desc]: position and level of every descriptor the root reaches (kPosNone for far-pointer slots, page headers, unused slots)
@@ -330,6 +393,17 @@ hipError_t launch_box_build(const uint64_t *descriptors, uint64_t n_desc, uint64
         hipLaunchKernelGGL(box_aux_kernel, dim3((unsigned)((cells + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, root_index, n, lc, boxes, aux);
         tick("table words", t0);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_box_check_cells(const uint64_t *descriptors, uint64_t root_index, int n, int lc, const uint32_t *aux, uint64_t samples,
+                                  uint64_t seed, unsigned long long *result, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipError_t e = hipMemsetAsync(result, 0, 2 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    if (!samples) return hipSuccess;
+    const unsigned tb = 256;
+    hipLaunchKernelGGL(box_check_cells_kernel, dim3((unsigned)((samples + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, root_index, n, lc, aux, samples, seed, result);
     return hipGetLastError();
 }
 

@@ -710,6 +710,9 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                     mode = ended();
                 } else {
                     const int b = locate(r.vx, r.vy, r.vz);
+#ifdef VRC_SCHED_STATS
+                    if (b >= 0) atomicAdd(&g_jump_stats[(kCoarse && top < lc) ? 10 : 11], 1ULL);   // empty nodes found above the table's level / below it
+#endif
                     if (b >= 0) {
                         enter_node(b);
                         r.distance_traveled++;            // :714

@@ -41,6 +41,9 @@ constexpr int kDefaultSafeStepsJump = VRC_DEFAULT_SAFE_STEPS_JUMP;      // ... o
 #define VRC_DEFAULT_JUMP_MIN_RUN 96
 #endif
 constexpr int kDefaultJumpMinRun = VRC_DEFAULT_JUMP_MIN_RUN, kDefaultJumpMinDepth = 12;
+// ... and with the empty boxes (round 5) the runs are longer: depth 11 then gains 13 % from the jumps (1.229 -> 1.069 ms, primary only
+// 0.847 -> 0.730), depth 10 and 9 still lose (0.562 -> 0.619, 0.546 -> 0.660)
+constexpr int kDefaultJumpMinDepthBoxes = 11;
 // ... and with the tables in LDS a jump is cheaper: 48 / 64 / 96 / 128 measured 2.56 / 2.50 / 2.52 / 2.53 ms on the headline frame
 // before the coarse table, 16 the best with it and 16-iteration safe runs (see kDefaultSafeStepsJump below)
 #ifndef VRC_DEFAULT_JUMP_MIN_RUN_LDS
