@@ -41,12 +41,12 @@ def make_map(rng, depth):
     return np.where(solid, mats, 0).astype(np.int8)
 
 
-def run(budget=300.0, seed=1, depths=(7, 8, 9), w=320, h=200):
+def run(budget=300.0, seed=1, depths=(7, 8, 9), w=320, h=200, limit=None):     # limit: stop after this many maps (fixed volume)
     """Returns (frames that differ, frames, maps)."""
     rng = np.random.default_rng(seed)
     atlas = vrc.synthetic_atlas()
     t0, frames, bad, maps = time.time(), 0, 0, 0
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (limit is None or maps < limit):
         depth = int(rng.choice(depths))
         dim = 1 << depth
         grid = make_map(rng, depth)

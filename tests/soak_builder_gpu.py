@@ -127,12 +127,12 @@ def run_grid(rng):
     return same, int(cnt)
 
 
-def run(budget=300.0, seed=1, depths=(6, 7, 8, 9, 10, 11)):
+def run(budget=300.0, seed=1, depths=(6, 7, 8, 9, 10, 11), limit=None):     # limit: stop after this many fields + grids (fixed volume)
     """Returns (fields with a difference, fields, descriptors compared)."""
     rng = np.random.default_rng(seed)
     t0, n, bad, total = time.time(), 0, 0, 0
     grids = 0
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (limit is None or n < limit):
         if rng.random() < 0.4:
             same, cnt = run_grid(rng)
             n += 1

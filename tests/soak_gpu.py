@@ -18,7 +18,7 @@ from oracle import orc  # noqa: E402
 from test_parity_gpu import hits_match, make_caster  # noqa: E402
 
 
-def run(budget=300.0, seed=1, depth=12, sc=None):
+def run(budget=300.0, seed=1, depth=12, sc=None, limit=None):     # limit: stop after this many poses (fixed volume; the budget is then a safety net)
     """Returns (mismatching bands, poses, rows compared).  tests/test_round3_gpu.py runs a 10-second slice of it."""
     rng = np.random.default_rng(seed)
     sc = sc or bench.build_scene(depth)
@@ -27,7 +27,7 @@ def run(budget=300.0, seed=1, depth=12, sc=None):
     # the tree, its coarse table and its boxes are uploaded / built ONCE and kept by this holder; every pose's caster adopts them
     holder = vrc.CLCaster()
     assert holder.init(0) and holder.assign_octree(sc["octree"]), holder.last_error()
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (limit is None or poses < limit):
         cam_pos = tuple(float(v) for v in (rng.random(3) * (dim * 1.2) - 0.1 * dim))
         if rng.random() < 0.5:                       # mostly above the terrain
             cx, cy = int(min(max(cam_pos[0], 0), dim - 1)), int(min(max(cam_pos[1], 0), dim - 1))

@@ -29,12 +29,12 @@ def setup(c, sc, tree, w, h, cam, li, settings, holder=None):
     assert ok, c.last_error()
 
 
-def run(budget=300.0, seed=1, depths=(8, 10, 12)):
+def run(budget=300.0, seed=1, depths=(8, 10, 12), limit=None):     # limit: stop after this many frames (fixed volume; the budget is then a safety net)
     """Returns (frames with a difference, frames)."""
     rng = np.random.default_rng(seed)
     scenes = {}
     t0, n, bad = time.time(), 0, 0
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (limit is None or n < limit):
         depth = int(rng.choice(depths))
         if depth not in scenes:
             sc = bench.build_scene(depth)

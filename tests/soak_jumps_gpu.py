@@ -21,7 +21,7 @@ OFF = 1 << 24
 SIZES = [(64, 48), (200, 120), (320, 200), (640, 360), (640, 360), (1000, 600), (1920, 1080)]
 
 
-def run(budget=300.0, seed=1, depths=(10, 12, 13, 14, 16), w=640, h=360, only=None, dump=False, vary_size=False):
+def run(budget=300.0, seed=1, depths=(10, 12, 13, 14, 16), w=640, h=360, only=None, dump=False, vary_size=False, limit=None):
     """Returns (frames that differ, frames, lane steps covered).  only: render just these frame numbers of the seeded
     sequence (replaying a run); dump: print the differing pixels with their hit records; vary_size: every caster gets a
     new viewport now and then (64x48 .. 1920x1080: from a dozen blocks to several times what the chip holds)."""
@@ -30,7 +30,7 @@ def run(budget=300.0, seed=1, depths=(10, 12, 13, 14, 16), w=640, h=360, only=No
     casters = {}
     size_rng, sizes_used = np.random.default_rng(seed + 1), {(w, h)}
     index = -1
-    while time.time() - t0 < budget and (only is None or index < max(only)):
+    while time.time() - t0 < budget and (only is None or index < max(only)) and (limit is None or frames < limit):   # limit: a fixed number of frames
         index += 1
         depth = int(rng.choice(depths))
         dim = 1 << depth

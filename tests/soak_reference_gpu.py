@@ -20,7 +20,7 @@ import test_reference_pin_gpu as pin  # noqa: E402
 import voxel_raycaster_amd as vrc  # noqa: E402
 
 
-def run(budget=300.0, seed=1):
+def run(budget=300.0, seed=1, limit=None):     # limit: stop after this many frames (fixed volume; the budget is then a safety net)
     """Returns (frames with a difference in what the primary ray decides, frames, statistics).  tests/test_round3_gpu.py
     runs a 10-second slice of it."""
     rng = np.random.default_rng(seed)
@@ -29,7 +29,7 @@ def run(budget=300.0, seed=1):
     atlas = vrc.synthetic_atlas()
     makers = [m for m in scenes.REFERENCE_KERNEL_SCENES if m is not scenes.terrain256]
     t0, frames, pixels, shaded, failures, totals = time.time(), 0, 0, 0, 0, {}
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (limit is None or frames < limit):
         s = dict(makers[int(rng.integers(len(makers)))]())
         dim = s["dim"]
         # a camera somewhere in or just outside the map, any direction; the reference's 20-step cap keeps what it sees local
