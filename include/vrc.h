@@ -252,7 +252,11 @@ int vrc_read_image_f32(vrc_caster *h, float *rgba, size_t n_floats);
  * pixel are read back.                                                                                              */
 int vrc_read_image_rgba8(vrc_caster *h, uint8_t *rgba, size_t n_bytes);
 /* 8 int32 per pixel: voxel x,y,z of the primary hit (-1 if none), material,
- * face bits, flags, final step count, canonical descriptor reads.            */
+ * face bits, flags, final step count, descriptor reads -- SURVEY 8(d)'s canonical
+ * count when the frame was rendered by the canonical traversal (setting
+ * empty_boxes = 0, trees without a coarse table, the array branch); with the
+ * tree's empty boxes (the default where they exist) the reads THAT traversal
+ * made: fewer, it skips nodes.  vrc_memory_usage2().empty_boxes says which.   */
 int vrc_read_hits(vrc_caster *h, int32_t *hits, size_t n_int32);
 #define VRC_HIT_FLAG_WRITTEN     1
 #define VRC_HIT_FLAG_SHADOW_CAST 2
@@ -268,7 +272,7 @@ int vrc_device_image(vrc_caster *h, void **dev_ptr, size_t *n_bytes);
 typedef struct vrc_counters {
     uint64_t primary_rays;
     uint64_t shadow_rays;
-    uint64_t descriptor_reads;   /* canonical count, SURVEY 8(d) */
+    uint64_t descriptor_reads;   /* SURVEY 8(d)'s canonical count, or the box traversal's own (see vrc_read_hits) */
     uint64_t texel_reads;
     uint64_t map_reads;
     uint64_t steps;
