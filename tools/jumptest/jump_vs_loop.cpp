@@ -101,11 +101,51 @@ static long check_pair_solve(std::mt19937_64 &rng, long n) {
     return bad;
 }
 
+// pair_probe + pair_count against the definition: the number of common values of Ma + i ia (i < ma) and Mb + j ib (j < mb), the index i
+// of the first and the index distance between them -- every value inside one binade (below 2^23), the increments 64 or more like the kernel's, the
+// starts anywhere (also further apart than the loop would ever leave them)
+static long check_pair_count(std::mt19937_64 &rng, long n) {
+    long bad = 0, several = 0, with_gcd = 0;
+    for (long c = 0; c < n; c++) {
+        const int kind = (int)(rng() % 6);
+        const int bits = 6 + (int)(rng() % (kind == 5 ? 17 : 9));
+        int32_t ia = 64 + (int32_t)(rng() % (1u << bits)), ib = 64 + (int32_t)(rng() % (1u << bits));
+        if (kind == 0) ib = ia;
+        if (kind == 1) { const int32_t g = 2 + (int32_t)(rng() % 60); ia = (ia / g + 1) * g; ib = (ib / g + 1) * g; }
+        if (kind == 2) ib = ia * (1 + (int32_t)(rng() % 4));
+        if (kind == 3) { const int32_t g = 128 + (int32_t)(rng() % 2000); ia = g * (1 + (int32_t)(rng() % 9)); ib = g * (1 + (int32_t)(rng() % 9)); }
+        const int32_t top = 1 << 23;
+        const int32_t Ma = (int32_t)(rng() % (uint32_t)(top - 1)), Mb = (rng() % 3 == 0) ? Ma + (int32_t)(rng() % 4) * (int32_t)ia % (top - Ma) : (int32_t)(rng() % (uint32_t)(top - 1));
+        const int32_t room_a = (top - 1 - Ma) / ia + 1, room_b = (top - 1 - Mb) / ib + 1;
+        const int32_t ma = 1 + (int32_t)(rng() % (uint32_t)room_a), mb = 1 + (int32_t)(rng() % (uint32_t)room_b);
+        int32_t sv, g;
+        pair_solve(true, ia, ib, sv, g);
+        const JumpEntry en = jump_entry_unpack(jump_entry_pack(sv, g, ib));
+        const PairProbe q = pair_probe(true, en, Ma, ma, Mb, ib);
+        PairTies t;
+        t.count = 0; t.first_i = 0; t.step_i = 1;
+        if (q.may) t = pair_count(q, Ma, ia, ma, Mb, ib, mb);
+        // the definition, by merging the two progressions
+        long want = 0, first = -1, step = -1, prev = -1;
+        for (int64_t i = 0, j = 0; i < ma && j < mb;) {
+            const int64_t va = (int64_t)Ma + i * ia, vb = (int64_t)Mb + j * ib;
+            if (va == vb) { if (!want) first = (long)i; else if (step < 0) step = (long)(i - prev); prev = (long)i; want++; i++; j++; }
+            else if (va < vb) i += std::max<int64_t>(1, (vb - va) / ia); else j += std::max<int64_t>(1, (va - vb) / ib);
+        }
+        bool ok = t.count == want && (!want || t.first_i == first) && (want < 2 || t.step_i == step);
+        several += want > 1; with_gcd += want > 0 && g > 1;
+        if (!ok) { if (bad < 10) printf("pair_count Ma=%d ia=%d ma=%d Mb=%d ib=%d mb=%d: %d from %d step %d, want %ld from %ld step %ld\n", Ma, ia, ma, Mb, ib, mb, t.count, t.first_i, t.step_i, want, first, step); bad++; }
+    }
+    printf("pair_count: %ld cases, %ld with several common values, %ld with a gcd above 1, mismatches %ld\n", n, several, with_gcd, bad);
+    return bad;
+}
+
 int main(int argc, char **argv) {
     long cases = argc > 1 ? atol(argv[1]) : 200000;
     unsigned seed = argc > 2 ? (unsigned)atoi(argv[2]) : 1;
     std::mt19937_64 rng(seed);
     if (check_pair_solve(rng, 5 * cases)) { printf("pair_solve mismatches\n"); return 1; }
+    if (check_pair_count(rng, 5 * cases)) { printf("pair_count mismatches\n"); return 1; }
     std::uniform_real_distribution<double> U(0.0, 1.0);
     long bad = 0;
     std::vector<Snap> trace;
