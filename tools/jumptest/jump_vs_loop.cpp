@@ -145,7 +145,7 @@ int main(int argc, char **argv) {
     unsigned seed = argc > 2 ? (unsigned)atoi(argv[2]) : 1;
     std::mt19937_64 rng(seed);
     if (check_pair_solve(rng, 5 * cases)) { printf("pair_solve mismatches\n"); return 1; }
-    if (check_pair_count(rng, 5 * cases)) { printf("pair_count mismatches\n"); return 1; }
+    if (check_pair_count(rng, cases)) { printf("pair_count mismatches\n"); return 1; }
     std::uniform_real_distribution<double> U(0.0, 1.0);
     long bad = 0;
     std::vector<Snap> trace;
