@@ -66,6 +66,35 @@ DEFK(andb, OP_AND) DEFK(lshl, OP_LSHL) DEFK(mov, OP_MOV) DEFK(rcp, OP_RCP) DEFK(
 DEFK(sqrtf, OP_SQRT) DEFK(floorf, OP_FLOOR) DEFK(rndne, OP_RNDNE) DEFK(cvtf, OP_CVTF) DEFK(mullo, OP_MULLO) DEFK(mulhi, OP_MULHI)
 DEFK(mul24, OP_MUL24) DEFK(subu, OP_SUBU) DEFK(cmpu, OP_CMPU) DEFK(cndv, OP_CNDV) DEFK(ffbh, OP_FFBH) DEFK(bcnt, OP_BCNT)
 
+// compare + select pairs (round 5): the select reading VCC (what the compiler's VOP2 forms use) against the same pair through
+// another SGPR pair; two instructions per OP, so the printed interval is per PAIR.  s[20:23] and vcc are declared clobbered.
+#define BODYC(OP)                                                                                          \
+    REP8(asm volatile(OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)                                       \
+                      : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k0), "v"(k1)  \
+                      : "vcc", "s20", "s21", "s22", "s23");)
+#define DEFKC(name, OP)                                                                                    \
+__global__ __launch_bounds__(256) void k_##name(float *out, unsigned long long *cyc, int iters) {          \
+    float r0 = threadIdx.x + 1.0f, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7; \
+    float k0 = 1.0001f, k1 = 0.5f;                                                                          \
+    const unsigned long long t0 = __builtin_readcyclecounter();                                             \
+    for (int i = 0; i < iters; i++) { BODYC(OP) }                                                           \
+    const unsigned long long t1 = __builtin_readcyclecounter();                                             \
+    out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;                            \
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                       \
+}
+#define OP_PAIRV(i)  "v_cmp_lt_f32 vcc, %" #i ", %9\n v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define OP_PAIRS(i)  "v_cmp_lt_f32 s[20:21], %" #i ", %9\n v_cndmask_b32 %" #i ", %" #i ", %8, s[20:21]\n"
+#define OP_PAIRS2(i) "v_cmp_lt_f32 s[20:21], %" #i ", %9\n v_cmp_gt_f32 s[22:23], %" #i ", %8\n v_cndmask_b32 %" #i ", %" #i ", %8, s[20:21]\n v_cndmask_b32 %" #i ", %" #i ", %9, s[22:23]\n"
+#define OP_PAIRV2(i) "v_cmp_lt_f32 vcc, %" #i ", %9\n v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n v_cmp_gt_f32 vcc, %" #i ", %8\n v_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
+#define OP_CNDV64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n"
+#define OP_CMPVADD(i) "v_cmp_lt_f32 vcc, %" #i ", %9\n v_add_f32 %" #i ", %" #i ", %8\n"
+#define OP_CNDVADD(i)   "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n v_add_f32 %" #i ", %" #i ", %9\n"
+#define OP_CNDV64ADD(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n v_add_f32 %" #i ", %" #i ", %9\n"
+#define OP_CNDVADD3(i)   "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n v_add_f32 %" #i ", %" #i ", %9\n v_mul_f32 %" #i ", %" #i ", %8\n v_add_f32 %" #i ", %" #i ", %9\n"
+#define OP_CNDV64ADD3(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n v_add_f32 %" #i ", %" #i ", %9\n v_mul_f32 %" #i ", %" #i ", %8\n v_add_f32 %" #i ", %" #i ", %9\n"
+DEFKC(cndvadd, OP_CNDVADD) DEFKC(cndv64add, OP_CNDV64ADD) DEFKC(cndvadd3, OP_CNDVADD3) DEFKC(cndv64add3, OP_CNDV64ADD3)
+DEFKC(pairv, OP_PAIRV) DEFKC(pairs, OP_PAIRS) DEFKC(pairs2, OP_PAIRS2) DEFKC(pairv2, OP_PAIRV2) DEFKC(cndv64, OP_CNDV64) DEFKC(cmpvadd, OP_CMPVADD)
+
 // packed f32 (two f32 operations per lane and instruction, 64-bit register pairs)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define BODY2(OP)                                                                                          \
@@ -136,6 +165,11 @@ int main() {
         {"v_cmp_lt_u32 vcc", k_cmpu}, {"v_cndmask_b32 (vcc)", k_cndv}, {"v_ffbh_u32", k_ffbh}, {"v_bcnt_u32_b32", k_bcnt},
         {"v_fma_f64", k_fma64}, {"v_mul_f64", k_mul64}, {"v_add_f64", k_add64}, {"v_floor_f64", k_floor64}, {"v_fract_f64", k_fract64},
         {"v_cvt_f64_i32", k_cvt_f64_i32}, {"v_cvt_i32_f64", k_cvt_i32_f64},
+        {"cmp vcc + cndmask vcc (pair)", k_pairv}, {"cmp s[20:21] + cndmask s[20:21] (pair)", k_pairs},
+        {"2 x (cmp, cndmask) via vcc (4 instr)", k_pairv2}, {"2 cmp s[20:23] then 2 cndmask (4 instr)", k_pairs2},
+        {"v_cndmask_b32_e64 ..., vcc", k_cndv64}, {"cmp vcc + v_add_f32 (pair)", k_cmpvadd},
+        {"cndmask e32 vcc + add (pair)", k_cndvadd}, {"cndmask e64 vcc + add (pair)", k_cndv64add},
+        {"cndmask e32 vcc + add, mul, add (4 instr)", k_cndvadd3}, {"cndmask e64 vcc + add, mul, add (4 instr)", k_cndv64add3},
         {"v_pk_fma_f32", k_pkfma}, {"v_pk_fma_f32 clamp", k_pkfmacl}, {"v_pk_add_f32", k_pkadd}, {"v_pk_mul_f32", k_pkmul}};
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
