@@ -15,7 +15,15 @@
  *     pointers re-read on every vrc_compute (reference: CL_MEM_USE_HOST_PTR,
  *     CLCaster.cpp:137-139,322) -- the caller keeps them alive.
  *   - a handle is not thread-safe (the reference is single-threaded, SURVEY
- *     8b).  A handle from vrc_create drives ONE GPU; multi-GPU is either one
+ *     8b): one host thread at a time per handle.  DIFFERENT handles may be
+ *     driven from different host threads, also when they hold one tree
+ *     (vrc_assign_octree_from): what is derived from a tree is built once under
+ *     the tree's guard, and a frame holds that guard from the moment it reads
+ *     the tree's pointers until its kernel is enqueued.  Holders of one tree
+ *     should agree on octree_root_index, octree_dimensions and coarse_log2: if
+ *     they differ every frame rebuilds the table and the boxes for ITS settings
+ *     (correct, but 0.6 s per frame at depth 12).
+ *     A handle from vrc_create drives ONE GPU; multi-GPU is either one
  *     such handle per GPU and process, each rendering its own row slice
  *     (vrc_set_row_slice), or ONE group handle from vrc_create_group that
  *     drives n GPUs from one host thread -- the reference's single synchronous
@@ -115,6 +123,15 @@ int vrc_create_texture_atlas(vrc_caster *h, const uint8_t *rgba8, int32_t width,
 /* CLCaster::assign_camera (CLCaster.cpp:133-143): direction = 2 floats
  * (inclination, azimuth), position = 3 floats.                              */
 int vrc_assign_camera(vrc_caster *h, const float *direction2, const float *position3);
+/* The sin / cos of the two camera angles, supplied by the host: trig4 = { sin(direction.x), cos(direction.x),
+ * sin(direction.y), cos(direction.y) }, the four values the reference kernel evaluates per pixel with the OpenCL
+ * library's sin / cos (ray_caster_kernel.cl:280-291).  RETAINED like the camera itself and re-read on every
+ * vrc_compute; NULL (the default) = the library evaluates sinf / cosf of the live direction on the host once per frame
+ * (SURVEY D2).  A host that evaluates them the way its reference build did -- or replays stored values, as
+ * tests/test_reference_vectors_gpu.py does with the reference kernel's own -- gets exactly that build's rays: the two
+ * libraries' results differ in the last bit for some angles, and one ulp of a direction is another ray table.
+ * vrc_release_camera drops the pointer with the camera.                                                              */
+int vrc_assign_camera_trig(vrc_caster *h, const float *trig4);
 /* CLCaster::release_camera (CLCaster.cpp:145-155) */
 int vrc_release_camera(vrc_caster *h);
 /* CLCaster::assign_lights (CLCaster.cpp:313-328): packed = 10 floats per light
@@ -159,8 +176,18 @@ int vrc_setting_get(vrc_caster *h, const char *name, int64_t *value);
 
 /* CLCaster::validate (CLCaster.cpp:157-206): checks that camera, map/octree,
  * viewport, lights and atlas are present and consistent.  No runtime
- * compilation happens: the kernels are prebuilt gfx950 code.                 */
+ * compilation happens: the kernels are prebuilt gfx950 code.  Where the
+ * reference pays its one-off cost (the kernel build, :157-206) this call pays
+ * ours: it ends with vrc_prepare, so the first vrc_compute costs a frame.      */
 int vrc_validate(vrc_caster *h);
+/* Builds what the SVO kernels derive from the tree for the current settings -- the dense table of the tree's top (setting
+ * coarse_log2) and the empty boxes (setting empty_boxes): 15 ms + 0.6 s for the 20 M descriptors of a 4096^3 terrain,
+ * 2.6 s at 8192^3 -- so that no frame has to.  Needs the octree and the settings octree_dimensions / using_octree;
+ * vrc_validate calls it.  Both structures are optional: a failed allocation is not an error (the frames are rendered by the
+ * kernels without them, vrc_memory_usage2().note says why).  A vrc_compute that finds them missing or built for other
+ * settings (root, depth, level changed after validate) still builds them itself, synchronously, inside that call -- also
+ * vrc_compute_async: it then blocks for the build.                                                                      */
+int vrc_prepare(vrc_caster *h);
 
 /* CLCaster::compute (CLCaster.cpp:224-228) -> run_kernel (:946-987).
  * Synchronous like the reference's clFinish (:970).                          */

@@ -28,6 +28,13 @@ int main(void) {
         if (vrc_create(0, &h) != VRC_OK || !h) return 6;
         if (vrc_validate(h) != VRC_ERR_NOT_READY) return 7;
         if (strstr(vrc_last_error(h), "camera") == NULL) return 8;
+        {   /* the host's own sin / cos of the camera angles: a retained pointer like the camera, NULL = the library's sinf / cosf;
+               nothing to prepare before an octree is assigned */
+            static const float trig[4] = {0.0f, 1.0f, 0.0f, 1.0f};
+            if (vrc_assign_camera_trig(h, trig) != VRC_OK || vrc_assign_camera_trig(h, NULL) != VRC_OK) return 14;
+            if (vrc_assign_camera_trig(NULL, trig) != VRC_ERR_INVALID_ARGUMENT) return 15;
+            if (vrc_prepare(h) != VRC_ERR_NOT_READY || vrc_prepare(NULL) != VRC_ERR_INVALID_ARGUMENT) return 16;
+        }
         {   /* the size-versioned memory report: a caller that knows fewer fields than the library gets only what its struct holds */
             vrc_memory2 m;
             unsigned char guard[sizeof(vrc_memory2) + 8];

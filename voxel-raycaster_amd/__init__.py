@@ -98,12 +98,14 @@ SIGNATURES = {
     "vrc_release_viewport": (C.c_int, [_H]),
     "vrc_create_texture_atlas": (C.c_int, [_H, _u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vrc_assign_camera": (C.c_int, [_H, _f32p, _f32p]),
+    "vrc_assign_camera_trig": (C.c_int, [_H, _f32p]),
     "vrc_release_camera": (C.c_int, [_H]),
     "vrc_assign_lights": (C.c_int, [_H, _f32p, _i32p]),
     "vrc_setting_add": (C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_int64]),
     "vrc_setting_set": (C.c_int, [_H, C.c_char_p, C.c_int64]),
     "vrc_setting_get": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_int64)]),
     "vrc_validate": (C.c_int, [_H]),
+    "vrc_prepare": (C.c_int, [_H]),
     "vrc_compute": (C.c_int, [_H]),
     "vrc_compute_async": (C.c_int, [_H]),
     "vrc_sync": (C.c_int, [_H]),
@@ -589,8 +591,20 @@ class CLCaster:
         self._keep["cam"] = (direction, position)
         return self._ok(lib.vrc_assign_camera(self._h, _ptr(direction, _f32p), _ptr(position, _f32p)))
 
+    def assign_camera_trig(self, trig: Optional[np.ndarray]) -> bool:
+        """trig: float32[4] = sin / cos of direction[0], sin / cos of direction[1] as the host evaluates them (the reference
+        kernel does it per pixel with the OpenCL library's, ray_caster_kernel.cl:280-291); retained and re-read at every
+        compute() like the camera.  None: the library's own sinf / cosf of the live direction (the default)."""
+        if trig is None:
+            self._keep.pop("trig", None)
+            return self._ok(lib.vrc_assign_camera_trig(self._h, None))
+        assert trig.dtype == np.float32 and trig.size == 4 and trig.flags["C_CONTIGUOUS"]
+        self._keep["trig"] = trig
+        return self._ok(lib.vrc_assign_camera_trig(self._h, _ptr(trig, _f32p)))
+
     def release_camera(self) -> bool:
         self._keep.pop("cam", None)
+        self._keep.pop("trig", None)
         return self._ok(lib.vrc_release_camera(self._h))
 
     def assign_lights(self, packed: np.ndarray, light_count: Optional[np.ndarray] = None) -> bool:
@@ -642,6 +656,11 @@ class CLCaster:
     # -- validate / compute (CLCaster.cpp:157-228)
     def validate(self) -> bool:
         return self._ok(lib.vrc_validate(self._h))
+
+    def prepare(self) -> bool:
+        """Builds what the SVO kernels derive from the tree (coarse table, empty boxes) for the current settings; validate()
+        ends with it, so this is for settings changed afterwards."""
+        return self._ok(lib.vrc_prepare(self._h))
 
     def compute(self) -> bool:
         return self._ok(lib.vrc_compute(self._h))

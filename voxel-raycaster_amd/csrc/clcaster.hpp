@@ -95,6 +95,9 @@ public:
     bool assign_camera(const Camera *camera) {                                                             // :133-143
         return ok(vrc_assign_camera(h_, camera->get_direction_pointer(), camera->get_position_pointer()));
     }
+    // extension: the sin / cos of the camera's two angles as THIS host evaluates them (the reference kernel evaluates them per
+    // pixel with the OpenCL library's, ray_caster_kernel.cl:280-291); four live floats, nullptr = the library's sinf / cosf
+    bool assign_camera_trig(const float *trig4) { return ok(vrc_assign_camera_trig(h_, trig4)); }
     bool release_camera() { return ok(vrc_release_camera(h_)); }                                          // :145-155
     bool assign_lights(std::vector<PackedData> *data) {                                                    // :313-328
         light_count_ = (int32_t)data->size();
@@ -117,7 +120,8 @@ public:
         return ok(vrc_setting_set(h_, setting_name.c_str(), *value));
     }
 
-    bool validate() { return ok(vrc_validate(h_)); }                                                       // :157-206
+    bool validate() { return ok(vrc_validate(h_)); }                                                       // :157-206 (ends with prepare())
+    bool prepare() { return ok(vrc_prepare(h_)); }        // the tree's derived structures for settings changed after validate()
     bool compute() { return ok(vrc_compute(h_)); }                                                         // :224-228
 
     // replaces draw(sf::RenderWindow*) (:330-332): the frame as float4 / RGBA8

@@ -68,8 +68,11 @@ struct vrc_tree {
     std::mutex guard;
     uint64_t *d_coarse = nullptr; uint64_t coarse_root = 0; int coarse_depth = 0, coarse_log2 = 0;
     uint32_t *d_boxes = nullptr, *d_box_aux = nullptr; uint64_t box_root = 0; int box_depth = 0, box_log2 = 0; double box_build_seconds = 0.0;
-    bool coarse_gave_up = false, boxes_gave_up = false;   // an allocation failed: the frames go on without (not retried every frame)
-    std::string note;                                     // why
+    // an allocation failed: the frames go on without the structure.  Not retried every frame -- but retried as soon as what was
+    // asked for changes (level, root, depth) or the host sets coarse_log2 / empty_boxes again (vrc_setting_add / _set)
+    bool coarse_gave_up = false, boxes_gave_up = false;
+    uint64_t coarse_fail_root = 0, box_fail_root = 0; int coarse_fail_depth = 0, coarse_fail_log2 = 0, box_fail_depth = 0, box_fail_log2 = 0;
+    std::string coarse_note, box_note;                    // why (cleared when the structure is built after all)
     ~vrc_tree() {
         // (the caller's current device is left as it was: a group that lets go of its peers' trees goes on allocating on rank 0's GPU)
         int cur = -1;
@@ -116,6 +119,7 @@ struct vrc_caster {
 
     // live (retained) host pointers
     const float *cam_dir = nullptr, *cam_pos = nullptr;
+    const float *cam_trig = nullptr;      // vrc_assign_camera_trig: the host's own sin / cos of the two angles (nullptr: sinf / cosf here)
     const float *lights = nullptr; const int32_t *light_count = nullptr;
 
     std::vector<vrc_setting> settings;    // <= 64 slots (include/CLCaster.h:303)
@@ -194,6 +198,8 @@ void mirror_tree(vrc_caster *h) {
     h->d_attach_lookup = t ? t->d_attach_lookup : nullptr; h->d_attach = t ? t->d_attach : nullptr; h->n_attach = t ? t->n_attach : 0;
 }
 
+int prepare_one(vrc_caster *h);           // (below, beside the launch path that shares derive_from_tree with it)
+
 int find_setting(const vrc_caster *h, const char *name) {
     for (size_t i = 0; i < h->settings.size(); i++)
         if (h->settings[i].name == name) return (int)i;
@@ -205,7 +211,16 @@ int64_t setting_or(const vrc_caster *h, const char *name, int64_t dflt) {
     return i < 0 ? dflt : h->settings[i].value;
 }
 
+// coarse_log2 / empty_boxes set (again) by the host: a build that failed before -- a transient out-of-memory, a level asked too
+// large -- is tried again by the next vrc_prepare / frame
+void retry_derived(vrc_caster *h, const char *name) {
+    if (!h->tree || (strcmp(name, "coarse_log2") != 0 && strcmp(name, "empty_boxes") != 0)) return;
+    std::lock_guard<std::mutex> lock(h->tree->guard);
+    h->tree->coarse_gave_up = h->tree->boxes_gave_up = false;
+}
+
 int set_setting(vrc_caster *h, const char *name, const char *define, int64_t value) {
+    retry_derived(h, name);
     int i = find_setting(h, name);
     if (i >= 0) { h->settings[i].value = value; return VRC_OK; }
     if (h->settings.size() >= 64) return fail(h, VRC_ERR_LIMIT, "settings buffer is full (64 slots)");
@@ -626,7 +641,10 @@ int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_
     // (the buffers belong to the TREE: every handle that shares it renders with the new materials from its next frame on)
     auto drop = [](vrc_caster *q) {
         vrc_tree *t = q->tree.get();
-        if (t) { (void)hipSetDevice(t->device); release(t->d_attach_lookup); release(t->d_attach); t->n_attach = 0; }
+        if (t) {
+            std::lock_guard<std::mutex> lock(t->guard);            // (another holder's frame copies these pointers under the guard)
+            (void)hipSetDevice(t->device); release(t->d_attach_lookup); release(t->d_attach); t->n_attach = 0;
+        }
         mirror_tree(q);
         q->validated = false;
     };
@@ -635,6 +653,7 @@ int vrc_assign_octree_attachments(vrc_caster *h, const uint32_t *lookup, uint64_
     HIP_TRY(h, hipSetDevice(h->device));
     vrc_tree *t = h->tree.get();
     if (have) {
+        std::lock_guard<std::mutex> lock(t->guard);
         HIP_TRY(h, hipMalloc((void **)&t->d_attach_lookup, n_lookup * sizeof(uint32_t)));
         HIP_TRY(h, hipMemcpy(t->d_attach_lookup, lookup, n_lookup * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMalloc((void **)&t->d_attach, n_attachments * sizeof(uint64_t)));
@@ -896,9 +915,16 @@ int vrc_assign_camera(vrc_caster *h, const float *direction2, const float *posit
     return VRC_OK;
 }
 
+int vrc_assign_camera_trig(vrc_caster *h, const float *trig4) {
+    if (!h) return VRC_ERR_INVALID_ARGUMENT;
+    h->cam_trig = trig4;                   // (NULL: back to sinf / cosf of the live direction)
+    FOR_PEERS(h, vrc_assign_camera_trig(q, trig4));
+    return VRC_OK;
+}
+
 int vrc_release_camera(vrc_caster *h) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
-    h->cam_dir = h->cam_pos = nullptr; h->validated = false;
+    h->cam_dir = h->cam_pos = nullptr; h->cam_trig = nullptr; h->validated = false;
     FOR_PEERS(h, vrc_release_camera(q));
     return VRC_OK;
 }
@@ -923,6 +949,7 @@ int vrc_setting_set(vrc_caster *h, const char *name, int64_t value) {
     if (!h || !name) return VRC_ERR_INVALID_ARGUMENT;
     int i = find_setting(h, name);
     if (i < 0) return fail(h, VRC_ERR_NOT_FOUND, "overwrite_setting: no setting named '%s'", name);   // CLCaster.cpp:1096-1100
+    retry_derived(h, name);
     h->settings[i].value = value;
     FOR_PEERS(h, vrc_setting_set(q, name, value));
     return VRC_OK;
@@ -976,7 +1003,22 @@ int vrc_validate(vrc_caster *h) {
     }
     if (h->atlas_w / h->tile_w <= 0 || h->atlas_h / h->tile_h <= 0) return fail(h, VRC_ERR_INVALID_ARGUMENT, "validate: tile larger than atlas");
     h->validated = true;
+    // the reference pays its one-off cost here (the kernel build, CLCaster.cpp:157-206); so do we: the structures the SVO kernels
+    // derive from the tree are built now, not inside the first frame.  (each rank of a group prepares in its own vrc_validate)
+    if (setting_or(h, "using_octree", 0) == 0) {
+        const int rc = prepare_one(h);
+        if (rc != VRC_OK) { h->validated = false; return rc; }
+    }
     FOR_PEERS(h, vrc_validate(q));
+    return VRC_OK;
+}
+
+int vrc_prepare(vrc_caster *h) {
+    if (!h) return VRC_ERR_INVALID_ARGUMENT;
+    const int rc = prepare_one(h);
+    if (rc != VRC_OK) return rc;
+    FOR_PEERS(h, prepare_one(q));
+    if (!h->peers.empty()) HIP_TRY(h, hipSetDevice(h->device));
     return VRC_OK;
 }
 
@@ -984,10 +1026,119 @@ int vrc_validate(vrc_caster *h) {
 
 namespace {
 
+// The structures the SVO kernels derive from a tree, for these settings: built when missing or built for another (root, depth,
+// level); the kernel parameters get the pointers.  The caller holds t->guard.  Both structures are optional accelerations: when
+// their memory cannot be had the frame is rendered without them (the table-less / box-less kernel instances); the reason is kept
+// with the tree and reported by vrc_memory_usage2, and the build is tried again when what is asked for changes.
+void derive_from_tree(vrc_caster *h, vrc_tree *t, int log2_dim, uint64_t root_index, int stepping_mode, vrc::RaycastParams &p) {
+    // the levels above coarse_log2 as a dense table (setting coarse_log2: -1 = by depth and tree size, 0 = none), read by both
+    // SVO kernels.  By default the finest level of the depth rule whose table is at most 16 x the descriptor array: a sparse
+    // tree in a large map does not get a table hundreds of times its own size
+    int64_t lc = setting_or(h, "coarse_log2", -1);
+    if (lc < 0) {
+        lc = vrc::coarse_level_for_depth(log2_dim);
+        while (lc >= 1 && ((uint64_t)sizeof(uint64_t) << (3 * lc)) > 16 * sizeof(uint64_t) * t->n_desc && ((uint64_t)sizeof(uint64_t) << (3 * lc)) > (1u << 20)) lc--;
+    }
+    lc = std::min<int64_t>(lc, std::min(log2_dim - 2, 10));
+    if (lc >= 1 && t->n_desc < (1ULL << 43)) {
+        if (!t->d_coarse || t->coarse_log2 != (int)lc || t->coarse_root != root_index || t->coarse_depth != log2_dim) {
+            release(t->d_coarse);
+            release(t->d_boxes); release(t->d_box_aux); t->box_log2 = 0;   // (the boxes' parallel word belongs to the table's cells)
+            t->coarse_log2 = 0;
+            const bool failed_before = t->coarse_gave_up && t->coarse_fail_log2 == (int)lc && t->coarse_fail_root == root_index && t->coarse_fail_depth == log2_dim;
+            if (!failed_before) {
+                hipError_t e = hipMalloc((void **)&t->d_coarse, sizeof(uint64_t) << (3 * lc));
+                if (e == hipSuccess) e = vrc::launch_coarse_build(t->d_desc, root_index, log2_dim, (int)lc, t->d_coarse, h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);          // other handles read it from their own streams
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    release(t->d_coarse);
+                    t->coarse_gave_up = true; t->coarse_fail_log2 = (int)lc; t->coarse_fail_root = root_index; t->coarse_fail_depth = log2_dim;
+                    t->coarse_note = std::string("no coarse table (level ") + std::to_string(lc) + "): " + hipGetErrorString(e) + "; ";
+                } else {
+                    t->coarse_log2 = (int)lc; t->coarse_root = root_index; t->coarse_depth = log2_dim;
+                    t->coarse_gave_up = false; t->coarse_note.clear();
+                }
+            }
+        }
+        if (t->d_coarse) { p.coarse = t->d_coarse; p.coarse_log2 = (int32_t)lc; }
+    } else if (t->d_coarse) {
+        release(t->d_coarse); t->coarse_log2 = 0;             // the setting went to "none": the table goes too
+        release(t->d_boxes); release(t->d_box_aux); t->box_log2 = 0;
+    }
+    // the empty boxes (empty_boxes.hip; setting empty_boxes: -1 = when the tree is small enough for them, 0 = never, 1 = always):
+    // 32 bytes per descriptor + 4 per table cell, built like the table they hang on; exact mode only.
+    // (Words for the table's cells ALONE -- boxes in the coarse space, octree nodes below it -- would fit any tree; measured:
+    // depth 12 1.71 ms against 1.50 with all words and 1.91 without, depth 14 -2 %, depth 16 +4 %: not offered.)
+    const int64_t want_boxes = setting_or(h, "empty_boxes", -1);
+    const bool box_ok = p.coarse != nullptr && stepping_mode == 0 && log2_dim <= 19 && t->n_desc < (1ULL << 31);
+    if (box_ok && (want_boxes > 0 || (want_boxes < 0 && t->n_desc <= (1ULL << 28)))) {
+        if (!t->d_boxes || t->box_log2 != (int)lc || t->box_root != root_index || t->box_depth != log2_dim) {
+            release(t->d_boxes); release(t->d_box_aux);
+            t->box_log2 = 0;
+            const bool failed_before = t->boxes_gave_up && t->box_fail_log2 == (int)lc && t->box_fail_root == root_index && t->box_fail_depth == log2_dim;
+            if (!failed_before) {
+                uint64_t *pos_tmp = nullptr;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                float ms = 0.f;
+                hipError_t e = hipMalloc((void **)&t->d_boxes, sizeof(uint32_t) * 8 * t->n_desc);
+                if (e == hipSuccess) e = hipMalloc((void **)&t->d_box_aux, sizeof(uint32_t) << (3 * lc));
+                if (e == hipSuccess) e = hipMalloc((void **)&pos_tmp, sizeof(uint64_t) * t->n_desc);
+                if (e == hipSuccess) e = hipEventCreate(&e0);
+                if (e == hipSuccess) e = hipEventCreate(&e1);
+                if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
+                if (e == hipSuccess) e = vrc::launch_box_build(t->d_desc, t->n_desc, root_index, log2_dim, (int)lc, pos_tmp, t->d_boxes, t->d_box_aux, h->stream);
+                if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                if (pos_tmp) (void)hipFree(pos_tmp);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    release(t->d_boxes); release(t->d_box_aux);
+                    t->boxes_gave_up = true; t->box_fail_log2 = (int)lc; t->box_fail_root = root_index; t->box_fail_depth = log2_dim;
+                    t->box_note = std::string("no empty boxes: ") + hipGetErrorString(e) + "; ";
+                } else {
+                    t->box_build_seconds = ms * 1e-3;
+                    t->box_log2 = (int)lc; t->box_root = root_index; t->box_depth = log2_dim;
+                    t->boxes_gave_up = false; t->box_note.clear();
+                }
+            }
+        }
+        if (t->d_boxes) { p.boxes = t->d_boxes; p.box_aux = t->d_box_aux; }
+    }
+    // (a handle that switches the boxes off keeps them: they belong to the tree, go with it, and a host that toggles the setting
+    // between frames -- tests/soak_jumps_gpu.py does -- must not pay the build again and again)
+}
+
+// vrc_prepare for one rank: the derived structures for the settings as they stand
+int prepare_one(vrc_caster *h) {
+    if (!h->have_octree || !h->tree) return fail(h, VRC_ERR_NOT_READY, "prepare: octree not assigned");
+    const int n = log2_exact(setting_or(h, "octree_dimensions", 0));
+    if (n < 1 || n > vrc::kMaxLevels) return fail(h, VRC_ERR_NOT_READY, "prepare: setting octree_dimensions missing or not a power of two in [2, 2^%d]", vrc::kMaxLevels);
+    const int64_t root = setting_or(h, "octree_root_index", 0);
+    if (root < 0 || (uint64_t)root >= h->tree->n_desc) return fail(h, VRC_ERR_INVALID_ARGUMENT, "prepare: octree_root_index out of range");
+    if (setting_or(h, "using_octree", 0) != 0) return VRC_OK;      // the array branch derives nothing
+    HIP_TRY(h, hipSetDevice(h->device));
+    vrc::RaycastParams p;
+    memset(&p, 0, sizeof(p));
+    std::lock_guard<std::mutex> lock(h->tree->guard);
+    derive_from_tree(h, h->tree.get(), n, (uint64_t)root, (int)setting_or(h, "stepping_mode", 0), p);
+    return VRC_OK;
+}
+
 int compute_async_one(vrc_caster *h) {
     if (!h->validated) return fail(h, VRC_ERR_NOT_READY, "compute: validate() has not succeeded");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->tree) mirror_tree(h);           // (a handle that shares the tree may have given it new materials since the last frame)
+    // The tree's guard is held from here until the kernel is ENQUEUED: another holder of the tree (another host thread, other
+    // settings, new materials) that replaces one of its arrays frees the old one with hipFree, which waits for the kernels already
+    // enqueued -- never for a frame that has copied the pointers and not launched yet (advisor finding, round 5).
+    std::unique_lock<std::mutex> tree_lock;
+    if (h->tree) {
+        tree_lock = std::unique_lock<std::mutex>(h->tree->guard);
+        mirror_tree(h);                    // (a handle that shares the tree may have given it new materials since the last frame)
+    }
 
     // settings stay live after validate() (CLCaster::overwrite_setting needs no recompile, CLCaster.cpp:1087-1109), so
     // the structural ones are checked again here: a bad value is an error return, never a device fault
@@ -1025,8 +1176,12 @@ int compute_async_one(vrc_caster *h) {
     p.root_index = (uint64_t)root;
     // live buffers are re-read every frame (CL_MEM_USE_HOST_PTR semantics)
     for (int a = 0; a < 3; a++) p.cam_pos[a] = h->cam_pos[a];
-    p.trig[0] = sinf(h->cam_dir[0]); p.trig[1] = cosf(h->cam_dir[0]);
-    p.trig[2] = sinf(h->cam_dir[1]); p.trig[3] = cosf(h->cam_dir[1]);
+    if (h->cam_trig) {                     // the host's own sin / cos (vrc_assign_camera_trig; ray_caster_kernel.cl:280-291)
+        for (int a = 0; a < 4; a++) p.trig[a] = h->cam_trig[a];
+    } else {
+        p.trig[0] = sinf(h->cam_dir[0]); p.trig[1] = cosf(h->cam_dir[0]);
+        p.trig[2] = sinf(h->cam_dir[1]); p.trig[3] = cosf(h->cam_dir[1]);
+    }
     // the reference binds light_count but shades with light 0 only (ray_caster_kernel.cl:264,660-670); setting
     // "light_count" (default 1) switches on the multi-light extension for the first n packed lights
     p.light_count = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(setting_or(h, "light_count", 1), *h->light_count),
@@ -1089,89 +1244,9 @@ int compute_async_one(vrc_caster *h) {
         h->partial_blocks = nblocks;
     }
     p.counters = h->d_partials;
-    if (svo) {
-        // What the kernels derive from the tree lives WITH the tree (vrc_tree): built here on first use, by the first handle that
-        // needs it, and whenever the root, the depth or the level asked for changed; shared by every handle that shares the array.
-        // Both structures are optional accelerations: when their memory cannot be had the frame is rendered without them (the
-        // table-less / box-less kernel instances), the reason is kept in vrc_tree::note and reported by vrc_memory_usage2.
-        vrc_tree *t = h->tree.get();
-        std::lock_guard<std::mutex> lock(t->guard);
-        // the levels above coarse_log2 as a dense table (setting coarse_log2: -1 = by depth and tree size, 0 = none), read by both
-        // SVO kernels.  By default the finest level of the depth rule whose table is at most 16 x the descriptor array: a sparse
-        // tree in a large map does not get a table hundreds of times its own size
-        int64_t lc = setting_or(h, "coarse_log2", -1);
-        if (lc < 0) {
-            lc = vrc::coarse_level_for_depth(p.log2_dim);
-            while (lc >= 1 && ((uint64_t)sizeof(uint64_t) << (3 * lc)) > 16 * sizeof(uint64_t) * t->n_desc && ((uint64_t)sizeof(uint64_t) << (3 * lc)) > (1u << 20)) lc--;
-        }
-        lc = std::min<int64_t>(lc, std::min(p.log2_dim - 2, 10));
-        if (lc >= 1 && t->n_desc < (1ULL << 43)) {
-            if (!t->d_coarse || t->coarse_log2 != (int)lc || t->coarse_root != p.root_index || t->coarse_depth != p.log2_dim) {
-                release(t->d_coarse);
-                release(t->d_boxes); release(t->d_box_aux); t->box_log2 = 0;   // (the boxes' parallel word belongs to the table's cells)
-                t->coarse_log2 = 0;
-                if (!t->coarse_gave_up) {
-                    hipError_t e = hipMalloc((void **)&t->d_coarse, sizeof(uint64_t) << (3 * lc));
-                    if (e == hipSuccess) e = vrc::launch_coarse_build(t->d_desc, p.root_index, p.log2_dim, (int)lc, t->d_coarse, h->stream);
-                    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);          // other handles read it from their own streams
-                    if (e != hipSuccess) {
-                        (void)hipGetLastError();
-                        release(t->d_coarse);
-                        t->coarse_gave_up = true;
-                        t->note = std::string("no coarse table (level ") + std::to_string(lc) + "): " + hipGetErrorString(e) + "; ";
-                    } else {
-                        t->coarse_log2 = (int)lc; t->coarse_root = p.root_index; t->coarse_depth = p.log2_dim;
-                    }
-                }
-            }
-            if (t->d_coarse) { p.coarse = t->d_coarse; p.coarse_log2 = (int32_t)lc; }
-        } else if (t->d_coarse) {
-            release(t->d_coarse); t->coarse_log2 = 0;             // the setting went to "none": the table goes too
-            release(t->d_boxes); release(t->d_box_aux); t->box_log2 = 0;
-        }
-        // the empty boxes (empty_boxes.hip; setting empty_boxes: -1 = when the tree is small enough for them, 0 = never, 1 = always):
-        // 32 bytes per descriptor + 4 per table cell, built on first use like the table they hang on; exact mode only.
-        // (Words for the table's cells ALONE -- boxes in the coarse space, octree nodes below it -- would fit any tree; measured:
-        // depth 12 1.71 ms against 1.50 with all words and 1.91 without, depth 14 -2 %, depth 16 +4 %: not offered.)
-        const int64_t want_boxes = setting_or(h, "empty_boxes", -1);
-        const bool box_ok = p.coarse != nullptr && p.stepping_mode == 0 && p.log2_dim <= 19 && t->n_desc < (1ULL << 31);
-        if (box_ok && (want_boxes > 0 || (want_boxes < 0 && t->n_desc <= (1ULL << 28)))) {
-            if (!t->d_boxes || t->box_log2 != (int)lc || t->box_root != p.root_index || t->box_depth != p.log2_dim) {
-                release(t->d_boxes); release(t->d_box_aux);
-                t->box_log2 = 0;
-                if (!t->boxes_gave_up) {
-                    uint64_t *pos_tmp = nullptr;
-                    hipEvent_t e0 = nullptr, e1 = nullptr;
-                    float ms = 0.f;
-                    hipError_t e = hipMalloc((void **)&t->d_boxes, sizeof(uint32_t) * 8 * t->n_desc);
-                    if (e == hipSuccess) e = hipMalloc((void **)&t->d_box_aux, sizeof(uint32_t) << (3 * lc));
-                    if (e == hipSuccess) e = hipMalloc((void **)&pos_tmp, sizeof(uint64_t) * t->n_desc);
-                    if (e == hipSuccess) e = hipEventCreate(&e0);
-                    if (e == hipSuccess) e = hipEventCreate(&e1);
-                    if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
-                    if (e == hipSuccess) e = vrc::launch_box_build(t->d_desc, t->n_desc, p.root_index, p.log2_dim, (int)lc, pos_tmp, t->d_boxes, t->d_box_aux, h->stream);
-                    if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
-                    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-                    if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
-                    if (e0) (void)hipEventDestroy(e0);
-                    if (e1) (void)hipEventDestroy(e1);
-                    if (pos_tmp) (void)hipFree(pos_tmp);
-                    if (e != hipSuccess) {
-                        (void)hipGetLastError();
-                        release(t->d_boxes); release(t->d_box_aux);
-                        t->boxes_gave_up = true;
-                        t->note += std::string("no empty boxes: ") + hipGetErrorString(e) + "; ";
-                    } else {
-                        t->box_build_seconds = ms * 1e-3;
-                        t->box_log2 = (int)lc; t->box_root = p.root_index; t->box_depth = p.log2_dim;
-                    }
-                }
-            }
-            if (t->d_boxes) { p.boxes = t->d_boxes; p.box_aux = t->d_box_aux; }
-        }
-        // (a handle that switches the boxes off keeps them: they belong to the tree, go with it, and a host that toggles the setting
-        // between frames -- tests/soak_jumps_gpu.py does -- must not pay the build again and again)
-    }
+    // What the kernels derive from the tree (the dense table of its top, the empty boxes) lives WITH the tree and is built by
+    // vrc_prepare / vrc_validate; a frame that finds it missing or built for other settings builds it here (under the guard).
+    if (svo) derive_from_tree(h, h->tree.get(), p.log2_dim, p.root_index, p.stepping_mode, p);
     // exact closed-form jumps: on from depth 12; the threshold depends on where the Euclid tables live (LDS when stack + tables
     // fit at full occupancy: depth 12)
     p.jump_tables_lds = (int32_t)std::min<int64_t>(2, std::max<int64_t>(0, setting_or(h, "jump_tables_lds", 2)));
@@ -1325,9 +1400,10 @@ int vrc_unpin_host_buffer(void *p) {
 int vrc_empty_boxes_check(vrc_caster *h, uint64_t samples, uint64_t seed, uint64_t *boxes_sampled, uint64_t *solid_voxels, double *build_seconds) {
     if (!h) return VRC_ERR_INVALID_ARGUMENT;
     vrc_tree *t = h->tree.get();
-    if (!t || !t->d_box_aux || !t->d_desc) return fail(h, VRC_ERR_NOT_READY, "empty_boxes_check: no boxes (setting empty_boxes, or no frame computed yet)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    if (!t) return fail(h, VRC_ERR_NOT_READY, "empty_boxes_check: no octree");
     std::lock_guard<std::mutex> lock(t->guard);
+    if (!t->d_box_aux || !t->d_desc) return fail(h, VRC_ERR_NOT_READY, "empty_boxes_check: no boxes (setting empty_boxes, or neither vrc_prepare nor a frame has run yet)");
+    HIP_TRY(h, hipSetDevice(h->device));
     uint64_t *pos = nullptr; unsigned long long *res = nullptr;
     hipError_t e = hipMalloc((void **)&res, 2 * sizeof(unsigned long long));
     unsigned long long out[2] = {0, 0}, cells[2] = {0, 0};
@@ -1356,7 +1432,9 @@ int vrc_empty_boxes_check(vrc_caster *h, uint64_t samples, uint64_t seed, uint64
 int vrc_read_empty_boxes(vrc_caster *h, uint64_t first_descriptor, uint64_t count, uint32_t *out) {
     if (!h || !out) return VRC_ERR_INVALID_ARGUMENT;
     vrc_tree *t = h->tree.get();
-    if (!t || !t->d_boxes) return fail(h, VRC_ERR_NOT_READY, "read_empty_boxes: no boxes (setting empty_boxes, or no frame computed yet)");
+    if (!t) return fail(h, VRC_ERR_NOT_READY, "read_empty_boxes: no octree");
+    std::lock_guard<std::mutex> lock(t->guard);
+    if (!t->d_boxes) return fail(h, VRC_ERR_NOT_READY, "read_empty_boxes: no boxes (setting empty_boxes, or neither vrc_prepare nor a frame has run yet)");
     if (first_descriptor > t->n_desc || count > t->n_desc - first_descriptor) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_empty_boxes: range past the array");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpy(out, t->d_boxes + 8 * first_descriptor, sizeof(uint32_t) * 8 * count, hipMemcpyDeviceToHost));
@@ -1382,7 +1460,7 @@ int vrc_memory_usage2(vrc_caster *h, int32_t rank, vrc_memory2 *out) {
         m.empty_boxes = q->last_frame_boxes ? 1 : 0;
         m.box_bytes = (t->d_boxes ? (uint64_t)sizeof(uint32_t) * 8 * t->n_desc : 0) + (t->d_box_aux ? (uint64_t)sizeof(uint32_t) << (3 * t->box_log2) : 0);
         m.box_build_seconds = t->box_build_seconds;
-        snprintf(m.note, sizeof(m.note), "%s", t->note.c_str());
+        snprintf(m.note, sizeof(m.note), "%s%s", t->coarse_note.c_str(), t->box_note.c_str());
     }
     const uint32_t n = std::min<uint32_t>(out->struct_size, (uint32_t)sizeof(m));
     m.struct_size = n;
