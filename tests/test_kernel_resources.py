@@ -69,11 +69,14 @@ def test_plain_instance_budget(kernels):
 def test_multi_light_instance_budget(kernels):
     """the multi-light instances carry the first-strike state (voxel, face position, mask * step, distance: ten
     dwords) through the shadow segments -- in scratch.  The item's time targets were met by the empty boxes; its
-    32-byte scratch target was not, and this budget keeps what there is from growing: 76 B (84 B with the boxes) at 5 waves per SIMD."""
+    32-byte scratch target was not, and this budget keeps what there is from growing: 84 B (100 B with the boxes) at 5 waves per SIMD.
+    (Round 6: the BYTES went from 84 to 100 with the boxes while the frame went from 3.66 to 3.19 ms with 4 lights -- the flat tie
+    section of exact_jump.hpp moved a cluster of 13 spill instructions out of the round loop.  What a spill costs is where it is
+    executed, not how many bytes the segment has; the byte budget only keeps the allocation from growing unnoticed.)"""
     for box in (True, False):
         k = kernels[svo(True, True, True, True, True, box)]
         assert k["vgpr_count"] <= 96
-        assert k["private_segment_fixed_size"] <= 88
+        assert k["private_segment_fixed_size"] <= 104
 
 
 def test_every_svo_instance_keeps_its_occupancy(kernels):

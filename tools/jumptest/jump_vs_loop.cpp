@@ -43,7 +43,7 @@ static long g_jumps = 0, g_jump_iters = 0, g_plain_iters = 0, g_fills = 0, g_par
 // returns false on a mismatch against the trace
 static bool jumped(State s, int left, int mix, const std::vector<Snap> &trace, Outcome &o, std::mt19937_64 &rng) {
     o = Outcome{};
-    uint32_t tab[kJumpTableDwords];
+    JumpWord tab[kJumpTableWords];
     memset(tab, 0xff, sizeof(tab));                // stale bytes everywhere: only rows marked in `rows` may be read
     uint32_t rows = 0;
     // now and then the table is not kept up (rows missing or cut off): those pairs must then be solved on the spot
@@ -120,7 +120,8 @@ static long check_pair_count(std::mt19937_64 &rng, long n) {
         const int32_t ma = 1 + (int32_t)(rng() % (uint32_t)room_a), mb = 1 + (int32_t)(rng() % (uint32_t)room_b);
         int32_t sv, g;
         pair_solve(true, ia, ib, sv, g);
-        const JumpEntry en = jump_entry_unpack(jump_entry_pack(sv, g, ib));
+        JumpEntry en = jump_entry_unpack(jump_entry_pack(sv, g, ib, recip_dd(ib)));
+        if (en.g == kJumpGcdEscape) { en.theta = jump_theta(sv, ib, recip_dd(ib)); en.g = g; }   // (what pair_ties does with the escape code)
         const PairProbe q = pair_probe(true, en, Ma, ma, Mb, ib);
         PairTies t;
         t.count = 0; t.first_i = 0; t.step_i = 1;
@@ -140,11 +141,39 @@ static long check_pair_count(std::mt19937_64 &rng, long n) {
     return bad;
 }
 
+// pair_probe's w against the definition (c * s) mod ib over the whole domain -- mantissa differences up to 2^23 either way, moduli up
+// to 2^23 inclusive (a delta_t just below the binade's power of two rounds to it), where the precision of the packed theta matters
+// most -- through the table word exactly as the kernel reads it
+static long check_pair_probe(std::mt19937_64 &rng, long n) {
+    long bad = 0, escapes = 0;
+    for (long c = 0; c < n; c++) {
+        const int kind = (int)(rng() % 6);
+        int32_t ib = (kind < 3) ? (1 << 23) - (int32_t)(rng() % (kind == 0 ? 16u : 1u << 22)) : 64 + (int32_t)(rng() % (1u << (6 + rng() % 18)));
+        int32_t ia = 64 + (int32_t)(rng() % ((1u << 23) - 63u));
+        if (kind == 4) { const int32_t g = 2 + (int32_t)(rng() % 5000); ia = std::max(1, ia / g) * g; ib = std::max(1, ib / g) * g; }
+        if (ia > (1 << 23)) ia = 1 << 23;
+        if (ib > (1 << 23)) ib = 1 << 23;
+        const int32_t Ma = (int32_t)(rng() % (1u << 23)), Mb = (kind == 5) ? (int32_t)(rng() % 3 == 0 ? 0 : (1 << 23) - 1) : (int32_t)(rng() % (1u << 23));
+        int32_t sv, g;
+        pair_solve(true, ia, ib, sv, g);
+        JumpEntry en = jump_entry_unpack(jump_entry_pack(sv, g, ib, recip_dd(ib)));
+        if (en.g == kJumpGcdEscape) { escapes++; en.theta = jump_theta(sv, ib, recip_dd(ib)); en.g = g; }
+        const PairProbe q = pair_probe(true, en, Ma, 1, Mb, ib);
+        const __int128 prod = (__int128)(Mb - Ma) * sv;
+        int64_t want = (int64_t)(prod % ib);
+        if (want < 0) want += ib;
+        if (q.w != (int32_t)want || q.g != g) { if (bad < 10) printf("pair_probe ia=%d ib=%d s=%d g=%d c=%d: w=%d g=%d, want %ld\n", ia, ib, sv, g, Mb - Ma, q.w, q.g, (long)want); bad++; }
+    }
+    printf("pair_probe: %ld cases (%ld through the gcd escape), mismatches %ld\n", n, escapes, bad);
+    return bad;
+}
+
 int main(int argc, char **argv) {
     long cases = argc > 1 ? atol(argv[1]) : 200000;
     unsigned seed = argc > 2 ? (unsigned)atoi(argv[2]) : 1;
     std::mt19937_64 rng(seed);
     if (check_pair_solve(rng, 5 * cases)) { printf("pair_solve mismatches\n"); return 1; }
+    if (check_pair_probe(rng, 10 * cases)) { printf("pair_probe mismatches\n"); return 1; }
     if (check_pair_count(rng, cases)) { printf("pair_count mismatches\n"); return 1; }
     std::uniform_real_distribution<double> U(0.0, 1.0);
     long bad = 0;

@@ -138,16 +138,17 @@ VRC_HD int32_t jump_axis_inc(int32_t e, float d, bool &halfway) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// per-ray table of the Euclid runs (jump_rows_build): one dword per (binade row, axis pair),
-//   row = e - kJumpFirstBinade (0 <= row < kJumpBinades), pairs xy, xz, yz:   tab[(3 * (row % kJumpRing) + pair) * stride]
+// per-ray table of the Euclid runs (jump_rows_build): one 8-byte word per (binade row, axis pair),
+//   row = e - kJumpFirstBinade (0 <= row < kJumpBinades), pairs xy, xz, yz:   tab[(3 * (row % R) + pair) * stride]
 // A ray's intersection_t only grow, so it needs the row of the binade it is in and those ahead: the table is a ring of
-// kJumpRing rows, and `rows` (a bit per row, kept by the caller) says which rows it holds right now.
-//   s and g = gcd(inc_a, inc_b) with s * inc_a == g (mod inc_b), 0 <= s < inc_b, packed by jump_entry_pack (two formats, see
-//   there);  whole dword 0: no entry.  (History: a second dword for the full gcd cost as much as it saved -- 88 instead of 72
-//   bytes of scratch, 1.0 instead of 0.67 GB of traffic; one variable-split format for every pair was 4 % slower with the tables
-//   in global memory: its decode sat on the hot path.)
+// R rows, and `rows` (a bit per row, kept by the caller) says which rows it holds right now.
+//   With s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib from the Euclid run, the word holds THETA = s / ib as a double and g
+//   (jump_entry_pack); whole word 0: no entry.  The hot path wants (c * s) mod ib for a mantissa difference c: that is
+//   ib * fract(c * theta), ONE fp64 product and a v_fract_f64 -- the modulus' reciprocal is a property of the row, not of the
+//   jump (rounds 3-5 kept s in a dword and every probe rebuilt 1 / ib: v_rcp_f32, a Newton step, a 48-bit product, floor, fma --
+//   a dependent fp64 chain of ~20 instructions per pair, 81 M times per headline frame).
 // The increments depend on (delta_t, binade) only.  In HBM (RaycastParams::jump_cache), one table per lane, interleaved
-// over the 64 lanes of a wave (stride 64) so that a row is one coalesced 256-byte line.
+// over the 64 lanes of a wave (stride 64) so that a row is coalesced 512-byte lines; in LDS [row][pair][thread].
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef VRC_JUMP_FIRST_LOG2
 #define VRC_JUMP_FIRST_LOG2 7
@@ -162,10 +163,12 @@ constexpr int kJumpBinades = 19 - VRC_JUMP_FIRST_LOG2;   // t < 2^19
 // 3 rows -- 9 KB -- were what fitted beside the 11-level traversal stack of a depth-12 tree before the coarse top table shrank
 // the stack (same speed on the headline frame, 3-4 % slower on deep trees whose rays cross more binades).
 constexpr int kJumpRing = VRC_JUMP_RING;      // the default R (host harness: -DVRC_JUMP_RING=3 / 4)
+struct alignas(8) JumpWord { uint32_t lo, hi; };   // one table entry (ds_read_b64 / global_load_dwordx2)
 template <int R> struct JumpRingMask;
-template <> struct JumpRingMask<3> { static constexpr uint32_t value = 0x09249249u; };   // a bit every R rows
+template <> struct JumpRingMask<2> { static constexpr uint32_t value = 0x55555555u; };   // a bit every R rows
+template <> struct JumpRingMask<3> { static constexpr uint32_t value = 0x09249249u; };
 template <> struct JumpRingMask<4> { static constexpr uint32_t value = 0x11111111u; };
-constexpr int kJumpTableDwords = 3 * kJumpRing;   // one dword per pair and row (default ring)
+constexpr int kJumpTableWords = 3 * kJumpRing;    // one word per pair and row (default ring)
 
 // s and g with s * ia == g (mod ib), g = gcd(ia, ib), 0 <= s < ib; 1 <= ia, ib < 2^24.  Extended Euclid on exact integers
 // held in floats, two steps per trip with the roles of the two remainders alternating (no conditional swaps):
@@ -221,40 +224,47 @@ VRC_HD void pair_solve(bool active, int32_t ia, int32_t ib, int32_t &s_out, int3
     while (VRC_WAVE_ANY(euclid_busy(c))) euclid_step(c);
     euclid_finish(c, ib, s_out, g_out);
 }
-struct JumpEntry { int32_t s, g; };            // g == 0: no entry
-// Two formats in one dword.  Small gcd (g <= 127, all but ~0.5 % of the pairs): s in bits 0-23, g in bits 24-30.  Large gcd: bit 31
-// set, bits 26-30 = (bits of g) - 8, then g, then s mod (ib / g) -- s is only ever multiplied with differences that g divides, so
-// it is needed modulo ib / g and the two together never take more than 26 bits.  (Until round 4 a gcd of 255 or more meant "solve
-// this pair afresh in every jump that meets it": 0.18 M such lanes made 8.6 M lanes of the headline frame wait for an
-// on-the-spot Euclid run.  The large format is written and decoded behind a wave vote: the hot path pays one compare.)
-VRC_HD uint32_t jump_entry_pack(int32_t s, int32_t g, int32_t ib) {
-    uint32_t d = (uint32_t)s | ((uint32_t)g << 24);
-    const bool big = g >= 128;
-    if (VRC_WAVE_ANY(big)) {
-        const int32_t gg = big ? g : 128;
-        int32_t rem, r2;
-        const int32_t ibr = floordiv(ib, gg, recip_d(gg), rem);           // exact: g divides ib
-        (void)floordiv(s, ibr > 0 ? ibr : 1, recip_d(ibr > 0 ? ibr : 1), r2);   // r2 = s mod (ib / g)
-        const uint32_t k = 32u - (uint32_t)__builtin_clz((uint32_t)gg);   // bits of g: 8 .. 24
-        if (big) d = 0x80000000u | ((k - 8u) << 26) | ((uint32_t)gg << (26u - k)) | (uint32_t)r2;
-    }
-    return d;
+// One table entry, decoded: theta = s / ib, g = gcd; g == 0: no entry, g == kJumpGcdEscape: the gcd did not fit (solve on the spot).
+struct JumpEntry { double theta; int32_t g; };
+constexpr int32_t kJumpGcdEscape = 2047;
+VRC_HD double bits2d(uint32_t lo, uint32_t hi) { union { double d; uint64_t u; } c; c.u = ((uint64_t)hi << 32) | lo; return c.d; }
+// 1 / b for an integer 1 <= b < 2^24 to ~2^-52 relative: hardware estimate + two Newton steps in fp64
+VRC_HD double recip_dd(int32_t b) {
+    const double bd = (double)b, r1 = recip_d(b);
+    return __builtin_fma(r1, __builtin_fma(-bd, r1, 1.0), r1);
 }
-VRC_HD JumpEntry jump_entry_unpack(uint32_t d) {
+// theta = s / ib to ~2^-52 (rb = recip_dd(ib)): product + one residual correction.  What the probes compute from it are
+// INTEGERS (pair_probe), and any theta within 2^-48 of s / ib gives the same ones: host and device need not agree on its last bits.
+VRC_HD double jump_theta(int32_t s, int32_t ib, double rb) {
+    const double sd = (double)s, q = sd * rb;
+    return __builtin_fma(__builtin_fma(-q, (double)ib, sd), rb, q);
+}
+// The word: theta's bit pattern with g in the 11 bits theta does not need.  0 <= theta < 1 and theta >= 2^-24 unless it is 0, so
+// the sign and the top five exponent bits are 0 01111 for every non-zero theta (biased exponents 999 .. 1022): bits 26-31 of the
+// high dword hold g >> 5.  The low five mantissa bits hold g & 31: below 2^-48 for every theta < 1, which is the precision
+// pair_probe needs (|c| < 2^23 and ib <= 2^23: |c| * ib * 2^-48 <= 1/4 of an integer).  theta == 0 decodes to ~2^-63: as good.
+// g above 2046 (3 pairs in 10 000: the gcd of two "random" increments is k with probability 6 / (pi k)^2): the escape code --
+// stretch_jump() solves such a pair afresh (as it does a pair whose row the ring has evicted).
+VRC_HD JumpWord jump_entry_pack(int32_t s, int32_t g, int32_t ib, double rb) {
+    union { double d; uint64_t u; } c;
+    c.d = jump_theta(s, ib, rb);
+    const uint32_t gc = (uint32_t)(g < kJumpGcdEscape ? g : kJumpGcdEscape);
+    JumpWord w;
+    w.lo = ((uint32_t)c.u & ~31u) | (gc & 31u);
+    w.hi = ((uint32_t)(c.u >> 32) & 0x03ffffffu) | ((gc >> 5) << 26);
+    return w;
+}
+VRC_HD JumpEntry jump_entry_unpack(JumpWord d) {
     JumpEntry en;
-    en.s = (int32_t)(d & 0xffffffu); en.g = (int32_t)(d >> 24);
-    const bool big = (int32_t)d < 0;
-    if (VRC_WAVE_ANY(big)) {
-        const uint32_t k = ((d >> 26) & 31u) + 8u, low = 26u - (k > 26u ? 26u : k);
-        if (big) { en.g = (int32_t)((d & 0x03ffffffu) >> low); en.s = (int32_t)(d & ((1u << low) - 1u)); }
-    }
+    en.g = (int32_t)(((d.hi >> 26) << 5) | (d.lo & 31u));
+    en.theta = bits2d(d.lo, (d.hi & 0x03ffffffu) | 0x3c000000u);
     return en;
 }
 
 // Builds one row (binade kJumpFirstBinade + row, the three pairs) of the table of every lane with `active` set; the
 // other lanes idle through the loop.  A pair one of whose axes cannot have a progression in that binade gets "no entry".
 template <int R = kJumpRing>
-VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float dz, uint32_t *tab, int stride, uint32_t &solves) {
+VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float dz, JumpWord *tab, int stride, uint32_t &solves) {
     const int32_t e = kJumpFirstBinade + row;
     const bool okx = active && jump_binade_ok(e, dx), oky = active && jump_binade_ok(e, dy), okz = active && jump_binade_ok(e, dz);
     bool hw;
@@ -267,17 +277,14 @@ VRC_HD void jump_table_build_row(bool active, int row, float dx, float dy, float
         euclid_step(cxy); euclid_step(cxz); euclid_step(cyz);
     }
     if (active) solves += (vxy ? 1u : 0u) + (vxz ? 1u : 0u) + (vyz ? 1u : 0u);
-    {   // (outside the `active` branch: the large-gcd format is packed behind a vote of the whole wave)
+    if (active) {
         int32_t s, g;
         const int slot = row % R;
-        euclid_finish(cxy, iy, s, g); const uint32_t dxy = jump_entry_pack(vxy ? s : 0, vxy ? g : 1, iy);
-        euclid_finish(cxz, iz, s, g); const uint32_t dxz = jump_entry_pack(vxz ? s : 0, vxz ? g : 1, iz);
-        euclid_finish(cyz, iz, s, g); const uint32_t dyz = jump_entry_pack(vyz ? s : 0, vyz ? g : 1, iz);
-        if (active) {
-            tab[(3 * slot + 0) * stride] = vxy ? dxy : 0u;
-            tab[(3 * slot + 1) * stride] = vxz ? dxz : 0u;
-            tab[(3 * slot + 2) * stride] = vyz ? dyz : 0u;
-        }
+        const double ry = recip_dd(iy), rz = recip_dd(iz);        // the two moduli's reciprocals (xz and yz share iz)
+        const JumpWord none = {0u, 0u};
+        euclid_finish(cxy, iy, s, g); tab[(3 * slot + 0) * stride] = vxy ? jump_entry_pack(s, g, iy, ry) : none;
+        euclid_finish(cxz, iz, s, g); tab[(3 * slot + 1) * stride] = vxz ? jump_entry_pack(s, g, iz, rz) : none;
+        euclid_finish(cyz, iz, s, g); tab[(3 * slot + 2) * stride] = vyz ? jump_entry_pack(s, g, iz, rz) : none;
     }
 }
 // rows stretch_jump() will read for these intersection_t: one per axis pair that shares a binade inside the table
@@ -296,7 +303,7 @@ VRC_HD uint32_t jump_rows_needed(float tx, float ty, float tz) {
 // lane's bit mask of built rows (cleared when the ray changes direction).
 template <int R = kJumpRing>
 VRC_HD void jump_rows_build(bool want, bool live, uint32_t &rows, float tx, float ty, float tz, float dx, float dy, float dz,
-                            uint32_t *tab, int stride, uint32_t &solves) {
+                            JumpWord *tab, int stride, uint32_t &solves) {
     uint32_t need = want ? (jump_rows_needed(tx, ty, tz) & ~rows) : 0u;
     // the lowest row this ray can still ask for: the binade of its smallest intersection_t (negative / tiny t: row 0)
     const float tmin = tx < ty ? (tx < tz ? tx : tz) : (ty < tz ? ty : tz);
@@ -316,61 +323,63 @@ VRC_HD void jump_rows_build(bool want, bool live, uint32_t &rows, float tx, floa
     }
 }
 // The packed entry of (pair, binade e), 0 for a row the table does not hold ("no entry").  The load is unconditional -- the ring
-// slot row % R always exists -- and the dword stays packed until pair_ties() needs it: a guarded load with the decode right behind
+// slot row % R always exists -- and the word stays packed until the probes need it: a guarded load with the decode right behind
 // it made every jump wait for three LDS round trips one after the other before its arithmetic started.  (A scheduling barrier
 // behind the three loads, so that none is sunk to its use: headline the same, the multi-light instances 3 % slower.)
 template <int R = kJumpRing>
-VRC_HD uint32_t jump_table_word(const uint32_t *tab, int stride, uint32_t rows, int pair, int32_t e) {
+VRC_HD JumpWord jump_table_word(const JumpWord *tab, int stride, uint32_t rows, int pair, int32_t e) {
     const uint32_t row = (uint32_t)(e - kJumpFirstBinade);
     const bool have = row < (uint32_t)kJumpBinades && ((rows >> (row & 31u)) & 1u);
-#ifdef VRC_JUMP_FAKE_TABLE   // (timing experiment only: no load, wrong tie counts)
-    return have ? (uint32_t)(12345 + pair) | (1u << 24) : 0u;
-#endif
-    const uint32_t d = tab[(3 * (int)(row % (uint32_t)R) + pair) * stride];
-    return have ? d : 0u;
+    JumpWord d = tab[(3 * (int)(row % (uint32_t)R) + pair) * stride];
+    d.lo = have ? d.lo : 0u; d.hi = have ? d.hi : 0u;
+    return d;
 }
 
 // One regular axis pair in a common binade: the consumed events are Ma + i*ia (0 <= i < ma) and Mb + j*ib (0 <= j < mb),
 // equal where i*ia - j*ib == c := Mb - Ma.  With the table's s*ia == g (mod ib): w = (c*s) mod ib equals g * i0 whenever g
 // divides c, i0 the smallest solution index -- so no solution lies below ma unless w < g * ma.
-// pair_probe() is the hot half (one modular product, straight-line so that the three pairs of a jump overlap);
-// pair_count() the warm half, entered only when a solution index may lie inside the stretch.
-struct PairProbe { int32_t w, s, g; bool may; };
+// pair_probe() is the hot half: w = ib * fract(c * theta) with the row's theta = s / ib -- a conversion, one fp64 product, a
+// v_fract_f64, one fma and a conversion back, no reciprocal and no floor / remainder fix-up (theta is good to 2^-48, |c| < 2^23, ib
+// <= 2^23: the product before rounding is within 0.27 of the integer w).  pair_count() is the warm half, entered only when a
+// solution index may lie inside the stretch.
+VRC_HD double fract_d(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fract(x);                             // v_fract_f64: x - floor(x), never 1.0
+#else
+    const double f = x - __builtin_floor(x);
+    return f < 1.0 ? f : 0x1.fffffffffffffp-1;
+#endif
+}
+struct PairProbe { int32_t w, g; bool may; };
 VRC_HD PairProbe pair_probe(bool active, JumpEntry entry, int32_t Ma, int32_t ma, int32_t Mb, int32_t ib) {
     PairProbe p;
-    p.s = active ? entry.s : 0;
     p.g = active ? entry.g : 1;
-    const int32_t m = active ? ib : 64;
-    // (c * s) mod m in [0, m): the 48-bit product is exact in fp64, its quotient estimate within 2^-20 of the true one
-    const double dm = (double)m, prod = (double)(Mb - Ma) * (double)p.s;
-    const double q = __builtin_floor(prod * recip_d(m));
-    int32_t r = (int32_t)__builtin_fma(-q, dm, prod);             // exact, in (-m, 2m)
-    r += (r < 0) ? m : 0;
-    r -= (r >= m) ? m : 0;
-    p.w = r;
-    p.may = active && (uint64_t)(uint32_t)r < (uint64_t)(uint32_t)ma * (uint64_t)(uint32_t)p.g;
+    const uint32_t m = (uint32_t)(active ? ib : 64);
+    const double f = fract_d((double)(Mb - Ma) * entry.theta);    // w / m, within 2^-25 (in [0, 1))
+    uint32_t r = (uint32_t)(int32_t)__builtin_fma(f, (double)m, 0.5);   // the nearest integer: 0 .. m
+    r = r < r - m ? r : r - m;                                    // (m -> 0: unsigned minimum of r and r - m)
+    p.w = (int32_t)r;
+    p.may = active && r < (uint32_t)ma * (uint32_t)p.g;           // (ma * g <= 2^23 + g: the consumed events lie in one binade)
     return p;
 }
 // number of equal values; first_i / step_i / the count describe them as i = first_i + k * step_i
 struct PairTies { int32_t count, first_i, step_i; };
-VRC_HD PairTies pair_count(const PairProbe &p, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
+// The usual tie case, decided on the hot path without a division or a vote: coprime increments and a stretch shorter than one
+// period of the solutions (ma <= ib and mb <= ia) -- i0 = w is the only candidate, and it counts when its partner index
+// j0 = (i0*ia - c) / ib lies in 0 .. mb-1.  j0 * ib = i0 * ia - c holds exactly (the congruence: g == 1 divides every c), so the test
+// is two products and two compares; i0 < ma and mb - 1 both index events inside the binade: the products stay below 2^24.
+// `general`: a solution index may lie inside the stretch and the case is not the usual one (pair_count_general, behind a vote).
+VRC_HD int32_t pair_count_quick(const PairProbe &q, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb, bool &general) {
+    const bool simple = (q.g == 1) & (ma <= ib) & (mb <= ia);
+    general = q.may & !simple;
+    const int32_t v = mul24(q.w, ia) - (Mb - Ma);                 // (meaningful for may & simple: w < ma)
+    return (q.may & simple & (v >= 0) & (v <= mul24((mb > 0 ? mb : 1) - 1, ib))) ? 1 : 0;
+}
+// The general count: a gcd above 1, or a stretch longer than one period of the solutions (in the terms below the usual case has
+// k_a = 0, k_b = 0 or negative, k_lo = 0 or positive).  Lanes without q.may idle through it.
+VRC_HD PairTies pair_count_general(const PairProbe &p, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
     PairTies out;
     out.count = 0; out.first_i = 0; out.step_i = 1;
-    // the usual case first: coprime increments and a stretch shorter than one period of the solutions (ma <= ib and
-    // mb <= ia): i0 = w is the only candidate, and it counts when its partner index j0 = (i0*ia - c) / ib (exact)
-    // lies in 0 .. mb-1.  (In the general form below k_a = 0, k_b = 0 or negative, k_lo = 0 or positive.)
-    const bool simple = p.g == 1 && ma <= ib && mb <= ia;
-#ifndef VRC_JUMP_NO_SIMPLE   // (A/B knob)
-    if (!VRC_WAVE_ANY(p.may && !simple)) {
-        if (p.may) {
-            int32_t rem;
-            const int32_t j0 = floordiv(mul24(p.w, ia) - (Mb - Ma), ib, recip_d(ib), rem);   // w < ma: w * ia < 2^24
-            out.count = (j0 >= 0 && j0 < mb) ? 1 : 0;
-            out.first_i = p.w; out.step_i = ib;
-        }
-        return out;
-    }
-#endif
     if (p.may) {
         const int32_t c = Mb - Ma, g = p.g;
         const double rg = recip_d(g);
@@ -390,27 +399,26 @@ VRC_HD PairTies pair_count(const PairProbe &p, int32_t Ma, int32_t ia, int32_t m
     }
     return out;
 }
-VRC_HD PairTies pair_ties(bool active, uint32_t word, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
-    JumpEntry entry = jump_entry_unpack(word);                    // (its large-gcd half is behind a vote of the whole wave)
-    const bool solve = active && entry.g == 0;                    // no entry: below t = 128, beyond the table, evicted
+// both halves for one pair (the host harness checks them against merged progressions; stretch_jump interleaves the three pairs)
+VRC_HD PairTies pair_count(const PairProbe &q, int32_t Ma, int32_t ia, int32_t ma, int32_t Mb, int32_t ib, int32_t mb) {
+    bool general;
+    PairTies out;
+    out.count = pair_count_quick(q, Ma, ia, ma, Mb, ib, mb, general); out.first_i = q.w; out.step_i = ib;
+    if (VRC_WAVE_ANY(general)) { PairProbe g = q; g.may = general; const PairTies t = pair_count_general(g, Ma, ia, ma, Mb, ib, mb); if (general) out = t; }
+    return out;
+}
+// a pair without a usable table entry -- below t = 128, beyond the table, evicted from the ring, a gcd the word cannot hold -- is
+// solved afresh (rare; behind a vote)
+VRC_HD bool jump_entry_missing(bool active, const JumpEntry &e) { return active & ((e.g == 0) | (e.g == kJumpGcdEscape)); }
+VRC_HD void jump_entry_solve(bool solve, JumpEntry &e, int32_t ia, int32_t ib) {
 #if defined(VRC_SCHED_STATS) && defined(__HIP_DEVICE_COMPILE__)
     if (solve) atomicAdd(&g_jump_private_solves[0], 1ULL);
-    if (VRC_WAVE_ANY(solve) && active && !solve) atomicAdd(&g_jump_private_solves[1], 1ULL);
 #endif
-    if (VRC_WAVE_ANY(solve)) {                                    // rare: solved on the spot
+    if (VRC_WAVE_ANY(solve)) {
         int32_t s2, g2;
         pair_solve(solve, solve ? ia : 64, solve ? ib : 64, s2, g2);
-        if (solve) { entry.s = s2; entry.g = g2; }
+        if (solve) { e.theta = jump_theta(s2, ib, recip_dd(ib)); e.g = g2; }
     }
-    const PairProbe q = pair_probe(active, entry, Ma, ma, Mb, ib);
-    PairTies out;
-    out.count = 0; out.first_i = 0; out.step_i = 1;
-#if defined(VRC_SCHED_STATS) && defined(__HIP_DEVICE_COMPILE__)
-    if (q.may) atomicAdd(&g_jump_private_solves[2], 1ULL);
-    if (VRC_WAVE_ANY(q.may) && active) atomicAdd(&g_jump_private_solves[3], 1ULL);
-#endif
-    if (VRC_WAVE_ANY(q.may)) out = pair_count(q, Ma, ia, ma, Mb, ib, mb);   // warm: a solution index may lie inside the stretch
-    return out;
 }
 
 struct JumpAxis {
@@ -500,12 +508,12 @@ struct JumpOut {
 // still run (max_distance - distance_traveled, >= 1).  `tab`, `stride`, `rows`: the ray's table (jump_rows_build).
 template <int R = kJumpRing>
 VRC_HD JumpOut stretch_jump(float &tx, float &ty, float &tz, float dx, float dy, float dz, int32_t &nx, int32_t &ny,
-                            int32_t &nz, int32_t left, const uint32_t *tab, int stride, uint32_t rows) {
+                            int32_t &nz, int32_t left, const JumpWord *tab, int stride, uint32_t rows) {
     // the table dwords first: their addresses need the exponents only, and the loads have the whole decode to arrive
     const int32_t ex0 = (int32_t)(f2u(tx) >> 23), ey0 = (int32_t)(f2u(ty) >> 23), ez0 = (int32_t)(f2u(tz) >> 23);
-    const uint32_t txy = jump_table_word<R>(tab, stride, ex0 == ey0 ? rows : 0u, 0, ex0);
-    const uint32_t txz = jump_table_word<R>(tab, stride, ex0 == ez0 ? rows : 0u, 1, ex0);
-    const uint32_t tyz = jump_table_word<R>(tab, stride, ey0 == ez0 ? rows : 0u, 2, ey0);
+    const JumpWord txy = jump_table_word<R>(tab, stride, ex0 == ey0 ? rows : 0u, 0, ex0);
+    const JumpWord txz = jump_table_word<R>(tab, stride, ex0 == ez0 ? rows : 0u, 1, ex0);
+    const JumpWord tyz = jump_table_word<R>(tab, stride, ey0 == ez0 ? rows : 0u, 2, ey0);
     JumpAxis ax = jump_axis(tx, dx, nx), ay = jump_axis(ty, dy, ny), az = jump_axis(tz, dz, nz);
     float X = ax.E < ay.E ? ax.E : ay.E;
     X = X < az.E ? X : az.E;
@@ -520,14 +528,34 @@ VRC_HD JumpOut stretch_jump(float &tx, float &ty, float &tz, float dx, float dy,
     PairTies pxy;
     pxy.count = 0; pxy.first_i = 0; pxy.step_i = 1;
 #ifndef VRC_JUMP_NO_TIES   // (timing experiment only: wrong iteration counts)
-    // one pair after the other: side by side the three modular products need more registers than the step loop leaves
-    // (measured: 116 instead of 68 bytes of scratch per lane and 0.25 ms)
-    if (VRC_WAVE_ANY(nxy)) {
-        pxy = pair_ties(nxy, txy, Mx, ax.inc, ax.m, My, ay.inc, ay.m);
-        ties += pxy.count;
+    {
+        // The three probes side by side -- each a conversion, an fp64 product, a fract, an fma: three independent chains -- and the
+        // usual tie case settled by pair_count_quick; votes only for what is rare: a pair without a usable entry, a tie case with a
+        // gcd or a long stretch.  (Rounds 3-5 took one pair after the other, each behind its own votes, "for the registers' sake":
+        // with the reciprocal chain gone from the probe the flat form needs no more registers, and the multi-light instances --
+        // whose spills it happened to move out of the round loop -- render 4 lights in 3.19 instead of 3.59 ms.)
+        JumpEntry exy = jump_entry_unpack(txy), exz = jump_entry_unpack(txz), eyz = jump_entry_unpack(tyz);
+        const bool sxy = jump_entry_missing(nxy, exy), sxz = jump_entry_missing(nxz, exz), syz = jump_entry_missing(nyz, eyz);
+        if (VRC_WAVE_ANY(sxy | sxz | syz)) {
+            jump_entry_solve(sxy, exy, ax.inc, ay.inc); jump_entry_solve(sxz, exz, ax.inc, az.inc); jump_entry_solve(syz, eyz, ay.inc, az.inc);
+        }
+        const PairProbe qxy = pair_probe(nxy, exy, Mx, ax.m, My, ay.inc), qxz = pair_probe(nxz, exz, Mx, ax.m, Mz, az.inc),
+                        qyz = pair_probe(nyz, eyz, My, ay.m, Mz, az.inc);
+        bool gen_xy, gen_xz, gen_yz;
+        pxy.count = pair_count_quick(qxy, Mx, ax.inc, ax.m, My, ay.inc, ay.m, gen_xy); pxy.first_i = qxy.w; pxy.step_i = ay.inc;
+        int32_t cxz = pair_count_quick(qxz, Mx, ax.inc, ax.m, Mz, az.inc, az.m, gen_xz);
+        int32_t cyz = pair_count_quick(qyz, My, ay.inc, ay.m, Mz, az.inc, az.m, gen_yz);
+#if defined(VRC_SCHED_STATS) && defined(__HIP_DEVICE_COMPILE__)
+        atomicAdd(&g_jump_private_solves[2], (unsigned long long)((qxy.may ? 1 : 0) + (qxz.may ? 1 : 0) + (qyz.may ? 1 : 0)));
+        if (gen_xy | gen_xz | gen_yz) atomicAdd(&g_jump_private_solves[3], 1ULL);
+#endif
+        if (VRC_WAVE_ANY(gen_xy | gen_xz | gen_yz)) {
+            if (VRC_WAVE_ANY(gen_xy)) { PairProbe q = qxy; q.may = gen_xy; const PairTies t = pair_count_general(q, Mx, ax.inc, ax.m, My, ay.inc, ay.m); if (gen_xy) pxy = t; }
+            if (VRC_WAVE_ANY(gen_xz)) { PairProbe q = qxz; q.may = gen_xz; const PairTies t = pair_count_general(q, Mx, ax.inc, ax.m, Mz, az.inc, az.m); if (gen_xz) cxz = t.count; }
+            if (VRC_WAVE_ANY(gen_yz)) { PairProbe q = qyz; q.may = gen_yz; const PairTies t = pair_count_general(q, My, ay.inc, ay.m, Mz, az.inc, az.m); if (gen_yz) cyz = t.count; }
+        }
+        ties += pxy.count + cxz + cyz;
     }
-    if (VRC_WAVE_ANY(nxz)) ties += pair_ties(nxz, txz, Mx, ax.inc, ax.m, Mz, az.inc, az.m).count;
-    if (VRC_WAVE_ANY(nyz)) ties += pair_ties(nyz, tyz, My, ay.inc, ay.m, Mz, az.inc, az.m).count;
 #endif
     // pairs outside the congruence: both last values equal X
     ties += (!gxy && ax.hitX && ay.hitX) ? 1 : 0;

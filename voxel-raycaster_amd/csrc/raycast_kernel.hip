@@ -39,7 +39,7 @@
 #include "safe_run.hpp"
 
 #ifndef VRC_LDS_RING
-#define VRC_LDS_RING 4                // rows of the Euclid-table ring when it lives in LDS (exact_jump.hpp: 3 or 4; with the coarse table the stack is 3 levels and 4 rows fit: 2.30 -> 2.29 ms)
+#define VRC_LDS_RING 3                // rows of the Euclid-table ring when it lives in LDS (exact_jump.hpp: 3 or 4).  Three 8-byte rows x 3 pairs = 72 bytes per lane: with the 36 bytes of a 3-level stack + index array that stays inside the 128 bytes per lane of 5 blocks per CU; four rows do not
 #endif
 #ifndef VRC_RELIGHT_THRESHOLD
 #define VRC_RELIGHT_THRESHOLD 64      // lanes that must wait for the next light before a wave with stepping lanes serves them
@@ -47,7 +47,7 @@
 
 namespace vrc {
 
-static_assert(3 * 4 == kJumpTableDwordsPerLane, "vrc_api.cpp sizes the global Euclid tables (4 ring rows x 3 pairs) with kJumpTableDwordsPerLane");
+static_assert(3 * 4 * (int)(sizeof(JumpWord) / sizeof(uint32_t)) == kJumpTableDwordsPerLane, "vrc_api.cpp sizes the global Euclid tables (4 ring rows x 3 pairs x 8 bytes) with kJumpTableDwordsPerLane");
 
 // Packed stack entry of one descriptor level:
 //   bits 0-7 valid mask, 8-15 leaf mask, 16-63 absolute index of the first kept child
@@ -361,13 +361,13 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
 
     // exact_jump.hpp: this lane's table of Euclid runs (one per binade and axis pair), interleaved over the wave's lanes,
     // and the bit mask of the rows built for the ray's current direction
-    uint32_t *jtab = nullptr;
+    JumpWord *jtab = nullptr;
     uint32_t jrows = 0;
-    // rows in LDS: behind the traversal stack, [ring row][pair][thread], one dword each (consecutive threads, consecutive banks)
+    // rows in LDS: behind the traversal stack, [ring row][pair][thread], one 8-byte word each (ds_read_b64 / ds_write_b64, consecutive threads)
     constexpr int kRing = kLdsTab ? VRC_LDS_RING : 4;    // table rows per ray (exact_jump.hpp)
     const int jstride = kLdsTab ? kBlockThreads : 64;
-    if (kLdsTab) jtab = lds_own + (kBox ? (size_t)(n - lc) * kBlockThreads : 0) + tid;
-    else if (kJump && s_jump_slot >= 0) jtab = p.jump_cache + ((size_t)s_jump_slot * kTilesPerBlock + (tid >> 6)) * (size_t)(3 * kRing * 64) + (tid & 63);
+    if (kLdsTab) jtab = reinterpret_cast<JumpWord *>(lds_own + (kBox ? (size_t)(n - lc) * kBlockThreads : 0)) + tid;   // (8-byte aligned: whole multiples of 1 KB before it)
+    else if (kJump && s_jump_slot >= 0) jtab = reinterpret_cast<JumpWord *>(p.jump_cache) + ((size_t)s_jump_slot * kTilesPerBlock + (tid >> 6)) * (size_t)(3 * kRing * 64) + (tid & 63);
 
     if (in_image) {
         if (!ray_setup(r, p, pix)) {
@@ -961,7 +961,7 @@ static size_t svo_stack_bytes(const RaycastParams &p) {
     // (with the boxes: a dword per level and thread for the descriptor index, behind the 8-byte entries)
     return (size_t)levels * kBlockThreads * (sizeof(uint64_t) + (svo_uses_boxes(p) ? sizeof(uint32_t) : 0)) + (size_t)p.lds_pad_bytes;
 }
-constexpr size_t kLdsTabBytes = (size_t)(3 * VRC_LDS_RING) * kBlockThreads * sizeof(uint32_t);   // ring rows x 3 pairs, one dword per thread
+constexpr size_t kLdsTabBytes = (size_t)(3 * VRC_LDS_RING) * kBlockThreads * sizeof(JumpWord);   // ring rows x 3 pairs, one 8-byte word per thread
 
 // Do the Euclid tables of this frame live in LDS?  Yes when the jump instance with stack + tables still reaches the blocks
 // per CU its registers allow (VRC_MIN_BLOCKS_JUMP) -- asked of the runtime once per LDS size; setting jump_tables_lds = 0 / 1

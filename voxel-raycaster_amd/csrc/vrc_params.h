@@ -51,7 +51,7 @@ constexpr int kDefaultJumpMinDepthBoxes = 11;
 #endif
 constexpr int kDefaultJumpMinRunLds = VRC_DEFAULT_JUMP_MIN_RUN_LDS;
 constexpr int kJumpOff = 1 << 24;      // jump_min_run >= this: the instances without the jump block
-constexpr int kJumpTableDwordsPerLane = 12;   // == kJumpTableDwords of exact_jump.hpp (checked in raycast_kernel.hip)
+constexpr int kJumpTableDwordsPerLane = 24;   // 4 ring rows x 3 pairs x one 8-byte word (exact_jump.hpp JumpWord; checked in raycast_kernel.hip)
 constexpr int kJumpSlotsPerXcd = 256;         // table slots per XCD: 32 CUs x 8 blocks, the most 256-thread blocks an XCD can hold at any occupancy
 constexpr int kJumpSlots = 8 * kJumpSlotsPerXcd;   // a block takes a slot of ITS XCD while it runs (the L2s of two XCDs are not coherent)
 constexpr int kMaxLights = 8;         // light slots (include/LightController.h:95)
@@ -78,8 +78,11 @@ inline uint64_t coarse_index(unsigned cx, unsigned cy, unsigned cz, int lc) {
     const uint64_t brick = (uint64_t)(cx >> k) | ((uint64_t)(cy >> k) << lb) | ((uint64_t)(cz >> k) << (2 * lb));
     return (brick << (3 * k)) | (cx & m) | ((cy & m) << k) | ((cz & m) << (2 * k));
 }
-// the table level for a tree of depth n (0: no table)
-constexpr int coarse_level_for_depth(int n) { return n >= 5 ? (n - 2 < kCoarseMaxLog2 ? n - 2 : kCoarseMaxLog2) : 0; }
+// the table level for a tree of depth n (0: no table).  From depth 16 on one level finer (1024^3 cells, 8 GB -- vrc_api.cpp only
+// takes it for trees of 0.5 GB and more): the traversal stack then has 6 levels, and stack + Euclid tables of the exact jumps
+// (exact_jump.hpp: 72 bytes per lane) still fit the 128 bytes of LDS a lane has at 5 blocks per CU; with 7 levels the tables
+// would move to global memory (depth 16, 1080p: 6.3 instead of 4.7 ms)
+constexpr int coarse_level_for_depth(int n) { return n >= 16 ? kCoarseMaxLog2 + 1 : n >= 5 ? (n - 2 < kCoarseMaxLog2 ? n - 2 : kCoarseMaxLog2) : 0; }
 
 // hit-record flag bits (include/vrc.h VRC_HIT_FLAG_*)
 constexpr int kFlagWritten = 1, kFlagShadowCast = 2, kFlagShadowHit = 4, kFlagOob = 8;
