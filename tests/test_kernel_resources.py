@@ -56,14 +56,17 @@ def test_headline_instance_budget(kernels):
     for box in (True, False):                          # round 5: the headline frame runs the instance with the empty boxes
         k = kernels[svo(True, False, True, True, True, box)]
         assert k["vgpr_count"] <= 96                       # 5 waves per SIMD
-        assert k["private_segment_fixed_size"] <= 40       # round 3: 76, round 4 before the ISA pass: 52, now 20 (28 with the boxes)
+        # round 3: 76 B, round 4: 20, round 5: 28 with the boxes, round 6: NONE -- the event phase no longer touches the ray's cold state
+        # (colours: settle_segment), voxel_step lives in three flag bits, the voxel is the cursor's, the cursor's entry is re-read from
+        # the LDS stack: 12 registers less through the round loop, and the 126 MB of spill write-backs per frame are gone
+        assert k["private_segment_fixed_size"] == 0
 
 
 def test_plain_instance_budget(kernels):
     for box in (True, False):
         k = kernels[svo(False, False, True, False, True, box)]  # trees below depth 12 (BASELINE configs[0], configs[1])
         assert k["vgpr_count"] <= 80                       # 6 waves per SIMD
-        assert k["private_segment_fixed_size"] <= 16
+        assert k["private_segment_fixed_size"] == 0
 
 
 def test_multi_light_instance_budget(kernels):
@@ -76,7 +79,7 @@ def test_multi_light_instance_budget(kernels):
     for box in (True, False):
         k = kernels[svo(True, True, True, True, True, box)]
         assert k["vgpr_count"] <= 96
-        assert k["private_segment_fixed_size"] <= 104
+        assert k["private_segment_fixed_size"] <= (64 if box else 84)   # all of it in the hit block and the relight block (tools/spill_map.py)
 
 
 def test_every_svo_instance_keeps_its_occupancy(kernels):

@@ -138,6 +138,22 @@ __device__ __forceinline__ void oob_exit(Ray &r) {
     r.flags |= kFlagOob;
 }
 
+// What oob_exit() / shadow_hit() do to the colour state, owed by a segment that ended in the SVO kernel's event phase (which only
+// sets kFlagOobPending / kFlagShadowPending): paid where the colours are touched anyway -- before the next light takes them as its
+// input (multi-light) and before the pixel is written.  distance_traveled is what it was when the ray left the map (a finished
+// segment no longer steps).  (The voxel correction of oob_exit has no reader there: the next segment starts from the strike.)
+__device__ __forceinline__ void settle_segment(Ray &r) {
+    if (r.flags & kFlagOobPending) {
+        const float k = 1.0f - max_cl((float)r.distance_traveled / 700.0f, 0.0f);
+#pragma unroll
+        for (int c = 0; c < 3; c++) r.color_accumulator[c] = mix_cl(0.0f, r.voxel_color[c], k);
+        r.color_accumulator[3] = mix_cl(0.0f, 0.0f, k);
+        r.color_accumulator[3] *= 4.0f;
+    }
+    if (r.flags & kFlagShadowPending) r.color_accumulator[3] = 0.1f;
+    r.flags &= ~(kFlagOobPending | kFlagShadowPending);
+}
+
 // :677-679 / :700-702: delta_t and intersection_t of a ray restarted at hit_pos (ray_dir, voxel_step already set)
 __device__ __forceinline__ void restart_from(Ray &r, Vec3 hit_pos) {
     r.dtx = fabsf(1.0f / r.rdx); r.dty = fabsf(1.0f / r.rdy); r.dtz = fabsf(1.0f / r.rdz);
@@ -292,6 +308,9 @@ __device__ __forceinline__ void ray_finish(Ray &r, const RaycastParams &p, unsig
     const long pix = cold_pixel_index(p, r.pix0);
     if (r.written) {
         const float k = 1.0f - max_cl(r.fog_distance / 700.0f, 0.0f);         // :716
+#ifdef VRC_NO_FRAME_STORE   // (traffic accounting only, tools/gpu_pmc_writes.sh: the frame is computed and not stored)
+        if (k == -123.0f)
+#endif
         reinterpret_cast<float4 *>(p.image)[pix] =
             make_float4(mix_cl(0.0f, r.color_accumulator[0], k), mix_cl(0.0f, r.color_accumulator[1], k),
                         mix_cl(0.0f, r.color_accumulator[2], k), mix_cl(0.0f, r.color_accumulator[3], k));

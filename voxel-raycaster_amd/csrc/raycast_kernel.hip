@@ -172,7 +172,10 @@ constexpr int kHwRegXccId = (3 << 11) | (0 << 6) | 20;
 //         empty_boxes = 0 renders with the canonical counter).  The cursor keeps the INDEX of the descriptor whose masks it holds
 //         in a second LDS array beside the stack ([level - lc][thread], one dword).
 template <bool kJump, bool kMulti, bool kTuned, bool kLdsTab = false, bool kCoarse = false, bool kBox = false>
-__global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
+#ifndef VRC_MIN_BLOCKS_JUMP_MULTI
+#define VRC_MIN_BLOCKS_JUMP_MULTI VRC_MIN_BLOCKS_JUMP
+#endif
+__global__ __launch_bounds__(kBlockThreads, kJump ? (kMulti ? VRC_MIN_BLOCKS_JUMP_MULTI : VRC_MIN_BLOCKS_JUMP) : VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
     static_assert(kJump || !kLdsTab, "tables exist for the jump instances only");
     static_assert(kCoarse || !kBox, "the boxes hang on the coarse table's cells");
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1  (kCoarse: [level-lc][thread], levels lc..n-1)
@@ -260,10 +263,10 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                 if (kBox) lds_own[tid] = own;
             }
         } else {
-            if (top > 0 && (diff >> (n - top)) != 0) {
-                top = n - (31 - __clz((int)diff)) - 1;    // deepest level whose node holds both voxels
-                cur = (!kCoarse && top == 0) ? root_entry : lds_stack[(top - sbase) * kBlockThreads + tid];
-            }
+            if (top > 0 && (diff >> (n - top)) != 0) top = n - (31 - __clz((int)diff)) - 1;   // deepest level whose node holds both voxels
+            // (the entry comes from the stack also when nothing is popped: one ds_read_b64 per event instead of two registers
+            // carried through the round loop -- every level from sbase down to `top` was stored on the way down)
+            cur = (!kCoarse && top == 0) ? root_entry : lds_stack[(top - sbase) * kBlockThreads + tid];
             if (kBox) own = lds_own[(top - sbase) * kBlockThreads + tid];   // (top >= lc here: a cursor above the table's level always takes the table)
         }
         pvx = x; pvy = y; pvz = z;
@@ -305,6 +308,13 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
 #define VRC_TUNED_WIDEN true
 #endif
     const bool widen = kTuned ? VRC_TUNED_WIDEN : p.widen_nodes != 0;
+    // voxel_step in the round loop: three bits of r.flags (kFlagStepShift); the voxel the cursor located last (pvx, pvy, pvz) is the
+    // ray's voxel from one event to the next -- Ray::sx.. / Ray::vx.. are set for the cold code where it is entered
+    auto step_pos = [&](int axis) -> bool { return (r.flags >> (kFlagStepShift + axis)) & 1; };
+    auto steps_to_flags = [&]() {
+        r.flags = (r.flags & ~kFlagStepMask) | ((r.sx > 0 ? 1 : 0) << kFlagStepShift) | ((r.sy > 0 ? 1 : 0) << (kFlagStepShift + 1)) | ((r.sz > 0 ? 1 : 0) << (kFlagStepShift + 2));
+    };
+    auto steps_from_flags = [&]() { r.sx = step_pos(0) ? 1 : -1; r.sy = step_pos(1) ? 1 : -1; r.sz = step_pos(2) ? 1 : -1; };
     // park the ray in the empty node of size 2^b around its voxel.  The parent's valid mask is at hand, so the
     // box is widened over empty siblings that lie ahead of the ray: fewer node events, same lookups (a sibling
     // the mask calls empty would have been found empty without any descriptor read).
@@ -313,23 +323,23 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         if (kBox) {
             // the node at (v & ~(size - 1)) extended by the box word's extents on the three sides the ray can leave through, clamped
             // to the map (beyond it everything is empty, but the :563 bounds test must see the crossing)
-            auto side = [&](int s, int v, int axis, int dim, int &base, float &count) {
-                const unsigned c = (boxw >> (unsigned)(5 * axis + (s > 0 ? 15 : 0))) & 31u;
+            auto side = [&](bool pos, int v, int axis, int dim, int &base, float &count) {
+                const unsigned c = (boxw >> (unsigned)(5 * axis + (pos ? 15 : 0))) & 31u;
                 const int ext = (c < 4u ? (int)c : (int)((4u | (c & 3u)) << ((c >> 2) - 1u))) << b;
                 const int o = v & ~(size - 1);
-                if (s > 0) { const int f = o + size + ext; base = f < dim ? f : dim; count = (float)(base - v); }
+                if (pos) { const int f = o + size + ext; base = f < dim ? f : dim; count = (float)(base - v); }
                 else { const int f = o - ext; base = (f > 0 ? f : 0) - 1; count = (float)(v - base); }
             };
-            side(r.sx, r.vx, 0, p.map_dim[0], bx, nx);
-            side(r.sy, r.vy, 1, p.map_dim[1], by, ny);
-            side(r.sz, r.vz, 2, p.map_dim[2], bz, nz);
+            side(step_pos(0), pvx, 0, p.map_dim[0], bx, nx);
+            side(step_pos(1), pvy, 1, p.map_dim[1], by, ny);
+            side(step_pos(2), pvz, 2, p.map_dim[2], bz, nz);
             return;
         }
         const unsigned valid = (unsigned)cur & 0xffu;
-        const int i = ((r.vx >> b) & 1) | (((r.vy >> b) & 1) << 1) | (((r.vz >> b) & 1) << 2);
+        const int i = ((pvx >> b) & 1) | (((pvy >> b) & 1) << 1) | (((pvz >> b) & 1) << 2);
         // axis a can be widened when the ray moves from this half of the parent toward the other half: child bit a differs
         // from the sign bit of the step (voxel_step is +1 or -1, never 0)
-        const unsigned sgn = (unsigned)((r.sx + 1) >> 1) | (unsigned)((r.sy + 1) & 2) | ((unsigned)((r.sz + 1) & 2) << 1);
+        const unsigned sgn = ((unsigned)r.flags >> kFlagStepShift) & 7u;
         const unsigned ahead = ((unsigned)i ^ sgn) & 7u;
         // children covered when widening over the axes in e = those that differ from i only in axes of e: the subsets of
         // e as bit positions (one byte per e in the constant), shifted to i with the axes of e cleared
@@ -345,17 +355,17 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             else if ((ahead & 4u) && (pair(4u) & valid) == 0) ext = 4u;
         }
         const int sx2 = (ext & 1u) ? 2 * size : size, sy2 = (ext & 2u) ? 2 * size : size, sz2 = (ext & 4u) ? 2 * size : size;
-        const int cx = r.vx & ~(sx2 - 1), cy = r.vy & ~(sy2 - 1), cz = r.vz & ~(sz2 - 1);
-        bx = r.sx > 0 ? cx + sx2 : cx - 1;
-        by = r.sy > 0 ? cy + sy2 : cy - 1;
-        bz = r.sz > 0 ? cz + sz2 : cz - 1;
+        const int cx = pvx & ~(sx2 - 1), cy = pvy & ~(sy2 - 1), cz = pvz & ~(sz2 - 1);
+        bx = step_pos(0) ? cx + sx2 : cx - 1;
+        by = step_pos(1) ? cy + sy2 : cy - 1;
+        bz = step_pos(2) ? cz + sz2 : cz - 1;
         // countdown = |base - voxel| (the step is +-1: no multiply needed)
-        nx = (float)(r.sx > 0 ? bx - r.vx : r.vx - bx); ny = (float)(r.sy > 0 ? by - r.vy : r.vy - by);
-        nz = (float)(r.sz > 0 ? bz - r.vz : r.vz - bz);
+        nx = (float)(step_pos(0) ? bx - pvx : pvx - bx); ny = (float)(step_pos(1) ? by - pvy : pvy - by);
+        nz = (float)(step_pos(2) ? bz - pvz : pvz - bz);
     };
-    // extent unknown (after a redirect, or inside solid): force an event after one step
-    auto enter_single = [&]() {
-        bx = r.vx + r.sx; by = r.vy + r.sy; bz = r.vz + r.sz;
+    // extent unknown (after a redirect, or inside solid): force an event after one step from voxel (x, y, z)
+    auto enter_single = [&](int x, int y, int z) {
+        bx = x + (step_pos(0) ? 1 : -1); by = y + (step_pos(1) ? 1 : -1); bz = z + (step_pos(2) ? 1 : -1);
         nx = ny = nz = 1.0f;
     };
 
@@ -379,9 +389,10 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             root_entry = make_entry(descriptors, p.root_index, d);
             cur = root_entry;
             int b = -1;
+            steps_to_flags();
             if (r.vx >= 0 && r.vy >= 0 && r.vz >= 0 && r.vx < p.map_dim[0] && r.vy < p.map_dim[1] && r.vz < p.map_dim[2])
                 b = locate(r.vx, r.vy, r.vz);             // the reference's per-pixel get_oct_vox (:342)
-            if (b >= 0) enter_node(b); else enter_single();
+            if (b >= 0) enter_node(b); else enter_single(r.vx, r.vy, r.vz);
             mode = (r.distance_traveled < r.max_distance) ? kStep : kDone;    // :357 guard
         }
     }
@@ -505,6 +516,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         }
 
         VRC_TICK(2);
+        asm volatile("; VRC_MARK safe_begin");
         // the arithmetic face_mask of the step loop needs every t to be 0 or >= 2^-100.  t only grows by
         // delta_t >= 1/2 per step, so once a lane is safe it stays safe until its ray is restarted (t_unsafe is set
         // again there); a wave with an unsafe stepping lane takes the compare/select loop for this burst.
@@ -588,6 +600,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         }
 
         VRC_TICK(3);
+        asm volatile("; VRC_MARK single_begin");
         // ---- phase 2b: one exact step for the lanes that are not deep inside a node.  A lane that has just reached
         // its safe-run threshold is almost always exactly one iteration from the node face (the threshold is within
         // n 2^-23 relative of the crossing time), and so is a lane in a freshly entered one-voxel node: one
@@ -612,6 +625,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             }
         }
 
+        asm volatile("; VRC_MARK exact_begin");
         // ---- phase 2: ordinary steps (:357-560) for lanes still inside their node.  A lane that is waiting
         // to jump only takes two steps (enough to settle its progressions); the others run to their node face.
         // (skipped when every stepping lane of the wave is still deep inside its node: the next safe run takes them on)
@@ -680,6 +694,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             }
         }
         VRC_TICK(4);
+        asm volatile("; VRC_MARK event_begin");
         const unsigned long long ev = __ballot(mode == kEvent);
         const unsigned long long st = __ballot(mode == kStep);
         unsigned long long sh = __ballot(mode == kShade || (kMulti && mode == kRelight));
@@ -700,16 +715,17 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                     atomicAdd(&g_run_hist[2][run_est_bucket], (unsigned long long)(L > 0 ? L : 0));
                 }
 #endif
-                r.vx = r.sx > 0 ? bx - (int)nx : bx + (int)nx;   // voxel = base - step * countdown, step = +-1
-                r.vy = r.sy > 0 ? by - (int)ny : by + (int)ny;
-                r.vz = r.sz > 0 ? bz - (int)nz : bz + (int)nz;
-                r.fmx = (int)fxf; r.fmy = (int)fyf; r.fmz = (int)fzf;
-                if (r.vx >= p.map_dim[0] || r.vy >= p.map_dim[1] || r.vz >= p.map_dim[2] || r.vx < 0 || r.vy < 0 || r.vz < 0) {
-                    oob_exit(r);                          // :563-568
-                    r.flags |= kFlagBroke;
+                const int vx = step_pos(0) ? bx - (int)nx : bx + (int)nx;   // voxel = base - step * countdown, step = +-1
+                const int vy = step_pos(1) ? by - (int)ny : by + (int)ny;
+                const int vz = step_pos(2) ? bz - (int)nz : bz + (int)nz;
+                // (the event phase touches nothing of the ray's COLD state -- colours, face_mask as the hit block wants it: what a segment
+                // that ends here owes the colours is flagged and paid by settle_segment(), the hit block gets its face_mask from the
+                // last step's mask when it runs)
+                if (vx >= p.map_dim[0] || vy >= p.map_dim[1] || vz >= p.map_dim[2] || vx < 0 || vy < 0 || vz < 0) {
+                    r.flags |= kFlagOob | kFlagOobPending | kFlagBroke;   // :563-568 (oob_exit)
                     mode = ended();
                 } else {
-                    const int b = locate(r.vx, r.vy, r.vz);
+                    const int b = locate(vx, vy, vz);
 #ifdef VRC_SCHED_STATS
                     if (b >= 0) atomicAdd(&g_jump_stats[(kCoarse && top < lc) ? 10 : 11], 1ULL);   // empty nodes found above the table's level / below it
 #endif
@@ -721,15 +737,14 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
                         note_entry();
 #endif
                     } else {
-                        mat = solid_material(r.vx, r.vy, r.vz);
-                        if ((mat == 5 || mat == 6) && r.shadow_ray) {   // :575, :707-710
-                            shadow_hit(r);
-                            r.flags |= kFlagBroke;
+                        mat = solid_material(vx, vy, vz);
+                        if ((mat == 5 || mat == 6) && r.shadow_ray) {   // :575, :707-710 (shadow_hit)
+                            r.flags |= kFlagShadowHit | kFlagShadowPending | kFlagBroke;
                             mode = ended();
                         } else if (mat == 5 || mat == 6) {
                             mode = kShade;                // the hit block is deferred
                         } else {                          // any other material is passed through
-                            enter_single();
+                            enter_single(vx, vy, vz);
                             r.distance_traveled++;        // :714
                             mode = (r.distance_traveled < r.max_distance) ? kStep : ended();   // :357
 #ifdef VRC_SCHED_STATS
@@ -743,6 +758,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         }
 
         VRC_TICK(5);
+        asm volatile("; VRC_MARK relight_begin");
         // ---- phase 4a (multi-light): a lane whose shadow ray has ended goes back to the first strike for the next light;
         // cheap next to the hit block, so it need not wait for the whole tile (VRC_RELIGHT_THRESHOLD lanes, or nothing left
         // to step)
@@ -750,15 +766,17 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             const unsigned long long rl = __ballot(mode == kRelight);
             if (rl != 0ULL && ((int)__popcll(rl) >= VRC_RELIGHT_THRESHOLD || __ballot(mode == kStep) == 0ULL)) {
             if (mode == kRelight) {
+                settle_segment(r);                        // what the ended shadow segment owes the colours: the next light's input
                 r.light_index++;
                 if (!light_from_strike(r, p, r.light_index, true)) {
                     mode = kDone;                         // :671-672, pixel left unwritten
                 } else {
                     restart_from(r, strike_pos(r));
+                    steps_to_flags();
                     t_unsafe = true;
                     steps_base += r.distance_traveled + ((r.flags >> kFlagBrokeShift) & 1) - (r.kdist + 1);
                     r.flags &= ~kFlagBroke;
-                    enter_single();
+                    enter_single(r.vx, r.vy, r.vz);
                     jrows = 0;                            // delta_t changed: the table of exact_jump.hpp is stale
                     r.distance_traveled = r.kdist + 1;    // as if the strike iteration had just finished (:714)
                     mode = (r.distance_traveled < r.max_distance) ? kStep : ended();
@@ -772,16 +790,23 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
         } else {
             sh = __ballot(mode == kShade);
         }
+        asm volatile("; VRC_MARK shade_begin");
         // ---- phase 4b: hit block (:575-711): expensive and needed once per pixel (a shadow ray's hit is handled where it
         // lands), so it runs only when the whole tile waits for it or nothing cheaper is left to do
         if (sh != 0ULL && (__ballot(mode == kStep) == 0ULL || (int)__popcll(sh) >= shade_threshold)) {
             VRC_STAT(w_sh_passes, 1); VRC_STAT(w_sh_lanes, __popcll(sh));
             if (mode == kShade) {
+                // what the hit block reads of the ray's hot state, handed over here: face_mask of the step that found the voxel (a parked
+                // lane has not stepped since), the voxel itself (the one the cursor located last), voxel_step
+                r.fmx = (int)fxf; r.fmy = (int)fyf; r.fmz = (int)fzf;
+                r.vx = pvx; r.vy = pvy; r.vz = pvz;
+                steps_from_flags();
                 if (hit_block<kMulti>(r, mat, p)) {
                     r.flags |= kFlagBroke;
                     mode = ended();
                 } else {
-                    enter_single();
+                    steps_to_flags();
+                    enter_single(r.vx, r.vy, r.vz);
                     t_unsafe = true;
                     jrows = 0;                            // delta_t changed with the redirect: the table of exact_jump.hpp is stale
                     r.distance_traveled++;                // :714
@@ -793,6 +818,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             }
         }
         VRC_TICK(6);
+        asm volatile("; VRC_MARK round_end");
     }
 
     const int tid_end = cold_thread_index(wave_in_block);  // threadIdx.x, without a register through the round loop
@@ -809,6 +835,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? VRC_MIN_BLOCKS_JUMP : VRC_MI
             c_tex = r.counts & 0xffu; c_shadow = (r.counts >> 8) & 0xffu;
             if (!r.written) c_unwritten = 1;
         }
+        settle_segment(r);
         ray_finish(r, p, c_desc);
     }
 #ifdef VRC_SCHED_STATS
@@ -992,7 +1019,7 @@ bool jump_tables_in_lds(const RaycastParams &p) {
         int per_cu = 0;
         const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlockThreads, lds);
         (void)hipGetLastError();
-        cached[slot] = e == hipSuccess && per_cu >= VRC_MIN_BLOCKS_JUMP;
+        cached[slot] = e == hipSuccess && per_cu >= (multi ? VRC_MIN_BLOCKS_JUMP_MULTI : VRC_MIN_BLOCKS_JUMP);
         cached_key[slot] = key;
     }
     return cached[slot];

@@ -90,6 +90,13 @@ constexpr int kFlagHasHit = 0x800;     // internal: the primary hit has been rec
 // internal, SVO kernel: what the counters need at the end of the ray, kept in the flags word instead of a register each --
 // the pixel cast a primary ray, the pixel stays unwritten (:293-294), the last segment ended by a break (one more iteration)
 constexpr int kFlagPrimary = 0x1000, kFlagUnwritten = 0x2000, kFlagBroke = 0x4000, kFlagBrokeShift = 14;
+// ... and what the end of a ray segment still owes the colour state (settle_segment in raycast_common.hpp): the ray left the map
+// (:563-568) / a shadow ray struck a voxel (:707-710).  The colours are cold state -- they live in scratch through the round loop --
+// and an assignment to them inside the event phase made the register allocator reload and re-spill them in EVERY event pass
+constexpr int kFlagOobPending = 0x8000, kFlagShadowPending = 0x10000;
+// ... and voxel_step as three bits (set: the ray steps +1 on that axis): the round loop of the SVO kernel reads the steps from here,
+// the cold code (hit block, relight) from Ray::sx/sy/sz, which it sets itself -- three registers less through the loop
+constexpr int kFlagStepShift = 17, kFlagStepMask = 7 << kFlagStepShift;
 
 // counters[] slots (device, uint64)
 enum CounterSlot {
