@@ -223,7 +223,12 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? (kMulti ? VRC_MIN_BLOCKS_JUM
     bool t_unsafe = true;                                 // see arith_mask below
     int steps_base = 0;                                   // iterations of the segments before the last reset (kMulti)
     // a ray segment ended (:357 guard, :563-568, :707-710)
-    auto ended = [&]() -> int { return (kMulti && more_lights(r, p)) ? kRelight : kDone; };
+    // (more_lights(r, p), with its light_index part kept as a flag bit by note_lights(): light_index is cold state, and read here it
+    // was reloaded from scratch in every step phase of the multi-light instances)
+    auto ended = [&]() -> int { return (kMulti && r.shadow_ray && r.written && (r.flags & kFlagMoreLights)) ? kRelight : kDone; };
+    auto note_lights = [&]() {
+        if (kMulti) r.flags = (r.flags & ~kFlagMoreLights) | ((p.shadow_rays && r.light_index + 1 < p.light_count) ? kFlagMoreLights : 0);
+    };
 
     // stepping state while inside a known-empty node: countdown of steps to the
     // node face per axis, voxel_a = base_a - s_a * n_a
@@ -768,6 +773,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? (kMulti ? VRC_MIN_BLOCKS_JUM
             if (mode == kRelight) {
                 settle_segment(r);                        // what the ended shadow segment owes the colours: the next light's input
                 r.light_index++;
+                note_lights();
                 if (!light_from_strike(r, p, r.light_index, true)) {
                     mode = kDone;                         // :671-672, pixel left unwritten
                 } else {
@@ -801,6 +807,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? (kMulti ? VRC_MIN_BLOCKS_JUM
                 r.fmx = (int)fxf; r.fmy = (int)fyf; r.fmz = (int)fzf;
                 r.vx = pvx; r.vy = pvy; r.vz = pvz;
                 steps_from_flags();
+                note_lights();                            // (light 0 is cast by the hit block: light_index is 0 here)
                 if (hit_block<kMulti>(r, mat, p)) {
                     r.flags |= kFlagBroke;
                     mode = ended();

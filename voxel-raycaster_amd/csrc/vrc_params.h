@@ -97,6 +97,9 @@ constexpr int kFlagOobPending = 0x8000, kFlagShadowPending = 0x10000;
 // ... and voxel_step as three bits (set: the ray steps +1 on that axis): the round loop of the SVO kernel reads the steps from here,
 // the cold code (hit block, relight) from Ray::sx/sy/sz, which it sets itself -- three registers less through the loop
 constexpr int kFlagStepShift = 17, kFlagStepMask = 7 << kFlagStepShift;
+// ... and (multi-light) "another light waits after this shadow segment": what more_lights() computes from light_index, kept as a bit
+// so that the step phases' `ended()` read no cold register
+constexpr int kFlagMoreLights = 0x100000;
 
 // counters[] slots (device, uint64)
 enum CounterSlot {
