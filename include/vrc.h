@@ -253,6 +253,8 @@ typedef struct vrc_memory2 {
     uint64_t coarse_bytes, box_bytes; /* per TREE, not per handle */
     double   box_build_seconds;
     char     note[160];               /* why an optional structure is missing (allocation failure), else empty */
+    uint64_t box_queries_cut;         /* region queries of the boxes' build that gave up at their budget of 4096 descents: the
+                                         boxes next to them are smaller than they could be (never wrong); 0 on every BASELINE scene */
 } vrc_memory2;
 int vrc_memory_usage2(vrc_caster *h, int32_t rank, vrc_memory2 *out);
 
@@ -265,7 +267,7 @@ int vrc_empty_boxes_check(vrc_caster *h, uint64_t samples, uint64_t seed, uint64
 /* The box words themselves: out[8 * i + k] belongs to child slot k = x | y<<1 | z<<2 of descriptor first_descriptor + i and
  * means something where that child is empty (not valid): six 5-bit extents, bits 0-4 -x, 5-9 -y, 10-14 -z, 15-19 +x, 20-24 +y,
  * 25-29 +z, in units of the child's own size; code c stands for c (c < 4), (4 | c & 3) << (c / 4 - 1) otherwise.  The box is
- * the child's cube widened by those extents, clamped to the map.  (tests/test_round5_gpu.py checks every voxel of every box of
+ * the child's cube widened by those extents, clamped to the map.  (tests/test_boxes_gpu.py checks every voxel of every box of
  * small trees against the dense grid on the host.)                                                                         */
 int vrc_read_empty_boxes(vrc_caster *h, uint64_t first_descriptor, uint64_t count, uint32_t *out);
 
@@ -308,6 +310,11 @@ typedef struct vrc_counters {
                                     kernel bug: vrc_get_counters then returns VRC_ERR_DEVICE, the frame is invalid */
 } vrc_counters;
 int vrc_get_counters(vrc_caster *h, vrc_counters *out);
+/* Which count descriptor_reads (and field 7 of the hit records) of the most recent frame is: *canonical = 1 when it is SURVEY
+ * 8(d)'s canonical count -- the array branch, trees without a coarse table, setting empty_boxes = 0 -- and 0 when the frame was
+ * rendered with the tree's empty boxes and the fields hold that traversal's own, smaller count.  So that one frame's records
+ * describe themselves (a host that compares them with the oracle or the reference reads this instead of guessing from settings). */
+int vrc_counters_canonical(vrc_caster *h, int32_t *canonical);
 
 /* Wave-scheduler statistics of the SVO kernel for the most recent frame (per wave, not per lane):
  * [0] step-loop iterations, [1] bursts, [2] node-event passes, [3] lanes serviced in them,

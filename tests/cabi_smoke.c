@@ -34,6 +34,10 @@ int main(void) {
             if (vrc_assign_camera_trig(h, trig) != VRC_OK || vrc_assign_camera_trig(h, NULL) != VRC_OK) return 14;
             if (vrc_assign_camera_trig(NULL, trig) != VRC_ERR_INVALID_ARGUMENT) return 15;
             if (vrc_prepare(h) != VRC_ERR_NOT_READY || vrc_prepare(NULL) != VRC_ERR_INVALID_ARGUMENT) return 16;
+            {   /* no frame yet: whatever counters there are, they are not a box traversal's */
+                int32_t canonical = -1;
+                if (vrc_counters_canonical(h, &canonical) != VRC_OK || canonical != 1) return 17;
+            }
         }
         {   /* the size-versioned memory report: a caller that knows fewer fields than the library gets only what its struct holds */
             vrc_memory2 m;

@@ -19,7 +19,7 @@ from test_parity_gpu import hits_match, make_caster  # noqa: E402
 
 
 def run(budget=300.0, seed=1, depth=12, sc=None, limit=None):     # limit: stop after this many poses (fixed volume; the budget is then a safety net)
-    """Returns (mismatching bands, poses, rows compared).  tests/test_round3_gpu.py runs a 10-second slice of it."""
+    """Returns (mismatching bands, poses, rows compared).  tests/test_soak_slices_gpu.py runs a 10-second slice of it."""
     rng = np.random.default_rng(seed)
     sc = sc or bench.build_scene(depth)
     dim, w, h = sc["dim"], 512, 288

@@ -21,7 +21,7 @@ import voxel_raycaster_amd as vrc  # noqa: E402
 
 
 def run(budget=300.0, seed=1, limit=None):     # limit: stop after this many frames (fixed volume; the budget is then a safety net)
-    """Returns (frames with a difference in what the primary ray decides, frames, statistics).  tests/test_round3_gpu.py
+    """Returns (frames with a difference in what the primary ray decides, frames, statistics).  tests/test_soak_slices_gpu.py
     runs a 10-second slice of it."""
     rng = np.random.default_rng(seed)
     probe = C.CDLL(os.path.join(pin.REF, "libref_probe.so"))

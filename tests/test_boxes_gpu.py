@@ -1,28 +1,23 @@
-"""Round 5 (-m gpu): the empty boxes of the exact kernel (csrc/empty_boxes.hip) and the per-tree state handles share.
+"""The empty boxes of the exact kernel (-m gpu; csrc/empty_boxes.hip) -- SURVEY 8 row a5: a derived structure like the coarse
+table.  Occupancy still comes from the descriptor array alone (Octree.h:89-94); inside a box the step loop of
+ray_caster_kernel.cl:555-570 reads no occupancy, so the float recurrence (:559), the iteration count (:714) and with them every
+pixel and every hit record are what they were.  Only the descriptor-read COUNT is the box traversal's own (field 7 of the hit
+records, counter descriptor_reads)."""
+import functools
+import os
+import resource
+import time
 
-The boxes are a derived structure like the coarse table: occupancy still comes from the descriptor array alone
-(Octree.h:89-94); inside a box the step loop of ray_caster_kernel.cl:555-570 reads no occupancy, so the float recurrence
-(:559), the iteration count (:714) and with them every pixel and every hit record are what they were.  Only the
-descriptor-read COUNT is the box traversal's own (field 7 of the hit records, counter descriptor_reads)."""
 import numpy as np
 import pytest
 
 import scenes
 import voxel_raycaster_amd as vrc
 from oracle import orc
+from gpu_helpers import _but_reads, _frame, _peak_rss_kb, _reset_peak_rss, _rss_now_kb, bench_scene, configure, lights4, survey_camera
 from test_parity_gpu import assert_same, hits_match, make_caster
 
 pytestmark = pytest.mark.gpu
-
-
-def _frame(c):
-    assert c.compute(), c.last_error()
-    return c.read_image().view(np.uint32).copy(), c.read_hits().copy(), c.counters()
-
-
-def _but_reads(ctr):
-    return {k: v for k, v in ctr.items() if k not in ("descriptor_reads", "canonical_reads")}
-
 
 @pytest.mark.parametrize("depth,lights,w,h", [(8, 1, 640, 360), (10, 2, 640, 360), (11, 1, 960, 540), (12, 1, 1920, 1080), (12, 4, 960, 540)],
                          ids=["d8", "d10-2lights", "d11", "d12-headline", "d12-4lights"])
@@ -107,48 +102,6 @@ def test_empty_boxes_exhaustive_check_on_a_small_tree(atlas):
         assert_same(cc.read_image(), cc.read_hits(), cc.counters(), oimg, ohits, octr)
 
 
-def test_trees_are_shared_not_copied():
-    """the coarse table and the boxes are functions of the TREE.  A second caster that adopts the first one's
-    tree (vrc_assign_octree_from) and the ranks of a same-GPU group hold ONE descriptor array, ONE table, ONE set of boxes;
-    frames are those of a caster with its own upload; the arrays outlive the handle that uploaded them."""
-    import bench
-    sc = bench.build_scene(10)
-    w, h = 640, 360
-    a = bench.make_caster(sc, w, h, 0)
-    ref = _frame(a)
-    ma = a.memory_usage2()
-    assert ma["tree_holders"] == 1 and ma["coarse_bytes"] > 0 and ma["box_bytes"] > 0 and ma["octree_shared"] == 0
-    b = vrc.CLCaster()
-    assert b.init(0)
-    for name, v in (("octree_dimensions", sc["dim"]), ("using_octree", 0), ("max_distance", 3 * sc["dim"])):
-        assert b.add_to_settings_buffer(name, name.upper(), v)
-    assert b.assign_octree_from(a), b.last_error()
-    assert (b.assign_camera(sc["cam_dir"], sc["cam_pos"]) and b.create_viewport(w, h) and b.assign_lights(sc["lights"])
-            and b.create_texture_atlas(sc["atlas"], (16, 16)) and b.validate()), b.last_error()
-    got = _frame(b)
-    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
-    mb = b.memory_usage2()
-    assert mb["tree_holders"] == 2 and mb["octree_shared"] == 1 and mb["coarse_bytes"] == ma["coarse_bytes"] and mb["box_bytes"] == ma["box_bytes"]
-    assert mb["box_build_seconds"] == ma["box_build_seconds"]        # not built a second time
-    del a                                                           # the uploader goes away: the tree stays with its last holder
-    import gc
-    gc.collect()
-    got = _frame(b)
-    assert np.array_equal(got[0], ref[0]) and b.memory_usage2()["tree_holders"] == 1
-    # an 8-rank group on one GPU: one tree between the ranks
-    g = vrc.CLCaster()
-    assert g.init_group([0] * 8, band_rows=8) and g.assign_octree(sc["octree"])
-    for name, v in (("octree_dimensions", sc["dim"]), ("using_octree", 0), ("max_distance", 3 * sc["dim"])):
-        assert g.add_to_settings_buffer(name, name.upper(), v)
-    assert (g.assign_camera(sc["cam_dir"], sc["cam_pos"]) and g.create_viewport(w, h) and g.assign_lights(sc["lights"])
-            and g.create_texture_atlas(sc["atlas"], (16, 16)) and g.validate()), g.last_error()
-    got = _frame(g)
-    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
-    mem = [g.memory_usage2(r) for r in range(8)]
-    assert all(m["tree_holders"] == 8 for m in mem) and [m["octree_shared"] for m in mem] == [0] + [1] * 7
-    assert len({m["box_build_seconds"] for m in mem}) == 1
-
-
 def test_optional_structures_fail_soft(atlas):
     """the table and the boxes are accelerations, not requirements.  A tree in a map too large for the default
     table gets a coarser one; with the table switched off there are no boxes and the frame is the same."""
@@ -165,37 +118,6 @@ def test_optional_structures_fail_soft(atlas):
     assert c.overwrite_setting("coarse_log2", -1)
     got = _frame(c)
     assert c.used_empty_boxes() and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
-
-
-def test_shared_tree_materials_follow_either_handle(atlas):
-    """Materials belong to the TREE (vrc_assign_octree_from's contract): assigned through one holder they are rendered by the
-    other from its next frame on -- mirrors and pass-through voxels appear -- and both frames equal the oracle's."""
-    from test_oracle_cpu import _with_pass_through
-    s = _with_pass_through(scenes.mirror_wall())
-    dim, w, h = s["dim"], 128, 96
-    plain = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000)
-    with_mat = vrc.Octree.Generate(s["grid"], dim, buffer_size=100000).attach_materials_from_grid(s["grid"])
-    a = make_caster(plain, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, 3 * dim)
-    b = make_caster(plain, dim, 0, s["cam_dir"], s["cam_pos"], s["lights"], atlas, w, h, 3 * dim, tree_from=a)
-    assert b.memory_usage2()["tree_holders"] == 2
-
-    def oracle(tree):
-        return orc.raycast(width=w, height=h, cam_dir=s["cam_dir"], cam_pos=s["cam_pos"], lights=a._li, atlas=atlas, tile_dim=(16, 16),
-                           descriptors=tree.descriptor_buffer, root_index=tree.root_index, octree_dim=dim, using_octree=0, max_distance=3 * dim,
-                           attachment_lookup=tree.attachment_lookup, attachments=tree.attachment_buffer)
-
-    assert b.compute(), b.last_error()
-    assert_same(b.read_image(), b.read_hits(), b.counters(), *oracle(plain))
-    assert a.assign_octree_attachments(with_mat) and a.validate() and b.validate()
-    for c in (b, a):
-        assert c.compute(), c.last_error()
-        oimg, ohits, octr = oracle(with_mat)
-        assert_same(c.read_image(), c.read_hits(), c.counters(), oimg, ohits, octr)
-    assert (ohits[..., 3] == 6).sum() > 0
-    # ... and taken away again through the OTHER holder
-    assert vrc.lib.vrc_assign_octree_attachments(b._h, None, 0, None, 0) == 0 and a.validate() and b.validate()
-    assert a.compute(), a.last_error()
-    assert_same(a.read_image(), a.read_hits(), a.counters(), *oracle(plain))
 
 
 @pytest.mark.parametrize("make", [scenes.random_sparse, scenes.floor_pillars, scenes.open_sky, scenes.terrain256],

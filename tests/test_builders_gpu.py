@@ -1,185 +1,67 @@
-"""GPU suite (-m gpu), round 3: slices of the two soaks inside the suite, the reference builder's own buffer layout
-through both branches, the exact closed-form jumps on every kind of frame."""
+"""SVO builders (-m gpu) -- SURVEY 8 rows a1 / a2 (descriptor format, Octree::Generate, src/map/Octree.cpp:13-43,171-323), f3
+((de)serialisation + streamed upload, Octree::Load include/map/Octree.h:38) and f4 (diamond-square terrain, src/map/Map.cpp:144-262):
+the device builders against the sequential host emitter bit for bit, trees in the reference builder's own buffer layout through
+both branches, device-built scenes and streamed uploads against the oracle.  Everything goes through the C ABI (libvrc.so)."""
+import functools
+import os
+import resource
+import time
+
 import numpy as np
 import pytest
 
 import scenes
 import voxel_raycaster_amd as vrc
 from oracle import orc
+from gpu_helpers import _but_reads, _frame, _peak_rss_kb, _reset_peak_rss, _rss_now_kb, bench_scene, configure, lights4, survey_camera
 from test_parity_gpu import assert_same, hits_match, make_caster
 
 pytestmark = pytest.mark.gpu
 
-
-# ------------------------------------------------------------------ soak slices (fixed seeds AND fixed volumes: the driver runs them)
-# (until round 5 these were time-budgeted -- what they covered depended on the box's speed; now every slice
-# renders a fixed number of poses / frames / maps, ~10 s each on an MI355X, and the time budget is only a safety net)
-def test_soak_slice_product_against_the_oracle():
-    """400 poses of tests/soak_gpu.py with a fixed seed: random camera poses / light sets / step caps in the depth-12
-    bench scene, exact mode (closed-form jumps on, the default at this depth) and mode B, single handles and 3-rank
-    groups, device RGBA8 pack -- whole 8-row tile bands against the oracle, bit for bit."""
-    import soak_gpu
-    bad, poses, rows = soak_gpu.run(budget=120.0, seed=20261002, depth=12, limit=400)
-    assert poses == 400 and rows == 400 * 24
-    assert bad == 0
-
-
-def test_soak_slice_reference_kernel_against_the_oracle():
-    """3000 frames of tests/soak_reference_gpu.py with a fixed seed: the reference's own raycaster kernel on the MI355X
-    (two image builtins redirected) against the oracle on random poses in the probe scenes."""
-    import os
-    import test_reference_pin_gpu as pin
-    if not os.path.exists(os.path.join(pin.REF, "ref_raycaster_gfx950_strict.co")):
-        pytest.fail("oracle/_ref/ is missing: build it with `make -C oracle _ref` where /root/reference exists")
-    import soak_reference_gpu
-    failures, frames, totals = soak_reference_gpu.run(budget=120.0, seed=20261002, limit=3000)
-    n = max(totals.get("shaded", 0), 1)
-    print(f"\nreference soak slice: {frames} frames, shaded pixels {totals.get('shaded', 0)}, rgb within 1e-5 "
-          f"{totals.get('rgb_1e-5', 0) / n:.6f}, within 1e-4 {totals.get('rgb_1e-4', 0) / n:.6f}")
-    assert frames == 3000 and failures == 0
-    assert totals.get("rgb_1e-5", 0) / n >= 0.999
+@pytest.mark.parametrize("depth,thickness,floor", [(3, 2, 2), (5, 2, 2), (6, 0, 2), (7, 3, 0), (8, 2, 2), (9, 7, 1), (10, 2, 2), (12, 2, 2)])
+def test_device_builder_equals_host_builder(depth, thickness, floor):
+    """vrc_build_shell_terrain: the array built in HBM is bit-identical to the sequential host emitter's brick
+    layout, Octree::Validate on the device finds no mismatch, and the device height field equals the procedural
+    column function."""
+    dim = 1 << depth
+    host, _ = vrc.shell_terrain_ex(depth, seed=1, thickness=thickness, octave_floor=floor, layout=vrc.LAYOUT_NO_PAGE_HEADERS)
+    c = vrc.CLCaster()
+    assert c.init(0)
+    rng = np.random.default_rng(depth)
+    probe = rng.integers(0, dim, size=(64, 2)).astype(np.int32)
+    counted, _ = c.build_shell_terrain(depth, 1, thickness, floor, count_only=True)
+    assert counted["n_descriptors"] == host.descriptor_buffer.size
+    info, lohi = c.build_shell_terrain(depth, 1, thickness, floor, validate_samples=1 << 20, probe_xy=probe)
+    assert info["n_descriptors"] == host.descriptor_buffer.size and info["root_index"] == host.root_index
+    assert info["validate_samples"] == 1 << 20 and info["validate_mismatches"] == 0
+    assert c.octree_size() == (host.descriptor_buffer.size, host.root_index)
+    dev = c.read_descriptors()
+    assert np.array_equal(dev, host.descriptor_buffer), f"{int((dev != host.descriptor_buffer).sum())} slots differ"
+    for (x, y), (lo, hi) in zip(probe, lohi):
+        assert (lo, hi) == vrc.shell_column(depth, x, y, seed=1, thickness=thickness, octave_floor=floor)
 
 
-def test_soak_slice_exact_jumps_on_small_frames_of_deep_scenes():
-    """1500 frames of tests/soak_jumps_gpu.py with a fixed seed: 640x360 frames (900 blocks: fewer than the chip holds,
-    the case in which blocks once handed their jump-table slots across XCDs and 1 frame in 4000 came back with a few
-    iteration counts off by one) of device-built depth-10 / 12 / 14 / 16 terrains, random poses, 1-4 lights, step caps and
-    jump thresholds, through the empty boxes where the tree has them (depths 10, 12) -- image, hit records and every counter equal
-    to the same frame stepped voxel by voxel from octree node to octree node."""
-    import soak_jumps_gpu
-    bad, frames, steps = soak_jumps_gpu.run(budget=150.0, seed=20261002, depths=(10, 12, 14, 16), limit=1500)
-    assert frames == 1500 and steps > 1e10
-    assert bad == 0
+def test_device_built_scene_renders_like_the_oracle(atlas):
+    """A frame of a device-built tree (depth 9, thick shell, survey camera with the octree bias active) against the
+    oracle rendering the host-built paged-layout tree of the same scene: the layout never shows in the picture."""
+    depth, thickness, w, h = 9, 6, 320, 200
+    dim = 1 << depth
+    cam_dir, cam_pos = survey_camera(depth, thickness=thickness)
+    c = vrc.CLCaster()
+    assert c.init(0)
+    c.build_shell_terrain(depth, 1, thickness, 2)
+    configure(c, dim, atlas, cam_dir, cam_pos, lights4(dim), w, h, light_count=2)
+    assert c.validate() and c.compute(), c.last_error()
+    host, _ = vrc.shell_terrain_ex(depth, thickness=thickness)     # the reference-style paged layout
+    oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas, tile_dim=(16, 16),
+                                    descriptors=host.descriptor_buffer, root_index=host.root_index, octree_dim=dim,
+                                    using_octree=0, max_distance=3 * dim, active_lights=2, threads=8)
+    assert hits_match(c, c.read_hits(), ohits)
+    assert np.array_equal(c.read_image().view(np.uint32), oimg.view(np.uint32))
+    ctr = c.counters()
+    assert (ctr["descriptor_reads"] == octr["n_desc"] or not ctr["canonical_reads"]) and ctr["steps"] == octr["n_steps"]
 
 
-def test_soak_slice_group_handle_against_the_single_handle():
-    """150 frames of tests/soak_groups_gpu.py with a fixed seed: 1-8 ranks on this GPU behind one handle (with and without
-    own copies of the tree), bands of 8..128 rows, frame sizes from 1x1 to 1920x1080 that are multiples of nothing, both
-    stepping modes, 1-4 lights, attachments, pinned and pageable read-back: frame, hit records, RGBA8 and counters equal
-    the single handle's."""
-    import soak_groups_gpu
-    bad, frames = soak_groups_gpu.run(budget=120.0, seed=20261002, depths=(8, 10), limit=150)
-    assert frames == 150 and bad == 0
-
-
-def test_soak_slice_device_builder_against_the_host_emitter():
-    """100 fields and grids of tests/soak_builder_gpu.py with a fixed seed: column fields the fixtures do not hold (white noise,
-    slabs, cliffs, floating pillars, single layers, solid maps, ceilings) at depths 6-9: the device-built array equals the
-    host emitter's bit for bit, the device validate passes, point queries of the tree agree with the field."""
-    import soak_builder_gpu
-    bad, fields, descriptors = soak_builder_gpu.run(budget=120.0, seed=20261002, depths=(6, 7, 8, 9), limit=100)
-    assert fields == 100 and descriptors > 0 and bad == 0
-
-
-def test_soak_slice_array_kernel_against_svo_kernel_on_device_built_trees():
-    """30 maps (1200 frames) of tests/soak_array_vs_svo_gpu.py with a fixed seed: random dense maps of 128^3 / 256^3 voxels with
-    materials and mirrors, the tree built on the device from the same grid (vrc_build_dense_grid + attachments), random
-    cameras inside the map: the array kernel's frame and the SVO kernel's frame (closed-form jumps forced on) are the
-    same image and the same hit records -- "SVO path == array path" beyond the sizes the oracle follows."""
-    import soak_array_vs_svo_gpu
-    bad, frames, maps = soak_array_vs_svo_gpu.run(budget=120.0, seed=20261002, depths=(7, 8), limit=30)
-    assert maps == 30 and frames >= 30 * 40 and bad == 0
-
-
-# ------------------------------------------------------------------ the array a reference host would pass
-@pytest.mark.parametrize("dim,density,seed", [(64, 0.5, 7), (128, 0.02, 5)], ids=["64^3-half-full", "128^3-sparse"])
-def test_strict_reference_buffer_through_both_branches(dim, density, seed, atlas):
-    """The nearest thing to consuming the reference builder's output: a tree in `strict_reference` layout -- the fixed
-    100 000-entry buffer filled from the end (include/map/Octree.h:29), all-ones page-header slots every 0x8000 entries
-    and far pointers (src/map/Octree.cpp:251-315), including the builder's own far-pointer quirks -- rendered through
-    the SVO branch and, with its dense twin, through the array branch; both equal the oracle and each other."""
-    rng = np.random.default_rng(seed)
-    grid = (rng.random(dim ** 3) < density).astype(np.int8) * 5
-    if dim == 64:
-        grid.reshape(dim, dim, dim)[dim // 2 - 2: dim // 2 + 2, :, :] = 0      # a corridor to look along
-    o = vrc.Octree.Generate(grid, dim, buffer_size=100000, strict_reference=True)
-    buf = o.descriptor_buffer
-    assert buf.size == 100000
-    far = int(((buf >> np.uint64(15)) & np.uint64(1))[buf != np.uint64(0xFFFFFFFFFFFFFFFF)].sum())
-    headers = int((buf == np.uint64(0xFFFFFFFFFFFFFFFF)).sum())
-    print(f"\nstrict tree {dim}^3: root at {o.root_index}, {int((buf != 0).sum())} non-zero slots, {far} far pointers, {headers} page headers")
-    assert headers > 0 and (far > 0 or dim == 64)                            # the layout features this test is about
-    # the oracle's builder produces the same array bit for bit (two independent implementations of Octree.cpp)
-    obuf, oroot = orc.octree_generate(grid, dim)
-    assert oroot == o.root_index and np.array_equal(obuf, buf)
-    w, h, md = 160, 120, 3 * dim
-    cam_pos, cam_dir = (dim / 2 + 0.31, 1.37, dim / 2 + 0.43), (1.45, 1.5708)
-    li = np.zeros((1, 10), dtype=np.float32)
-    li[0] = [0.01, 0.01, 0.01, 0.2, dim * 0.8, dim * 0.2, dim * 0.9, 0, 0, -1]
-    frames = []
-    for using_octree in (0, 1):
-        c = make_caster(o, dim, using_octree, cam_dir, cam_pos, li, atlas, w, h, md, grid=grid)
-        assert c.compute(), c.last_error()
-        oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas, tile_dim=(16, 16),
-                                        descriptors=buf, root_index=o.root_index, octree_dim=dim, using_octree=using_octree,
-                                        grid=grid, max_distance=md)
-        img, hits = c.read_image(), c.read_hits()
-        assert_same(img, hits, c.counters(), oimg, ohits, octr)
-        frames.append((img, hits))
-    assert (frames[0][1][..., 3] == 5).sum() > 1000
-    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
-    assert np.array_equal(frames[0][1][..., :7], frames[1][1][..., :7])       # (the descriptor-read count differs by construction)
-
-
-# ------------------------------------------------------------------ exact closed-form jumps: identical frames
-@pytest.mark.parametrize("depth,lights,k", [(10, 1, 8), (12, 1, 96), (12, 4, 32), (13, 2, 96)],
-                         ids=["d10-K8", "d12-default", "d12-4lights-K32", "d13-2lights"])
-def test_exact_jumps_leave_the_frame_bit_identical(depth, lights, k):
-    """exact_jump.hpp inside the step kernel: the frame -- image, hit records, every counter -- with jumps is the frame
-    without them, on whole 1080p frames (primary + shadow rays, multi-light relighting, mirrors via attachments at depth
-    10), whatever the threshold."""
-    import bench
-    sc = bench.build_scene(depth)
-    tree = sc["octree"]
-    if depth == 10 and tree.attachment_lookup is None:
-        tree.attach_materials_procedural(depth, seed=1, mirror_period=64)
-    c = bench.make_caster(sc, 1920, 1080, 0, light_count=lights)
-    assert c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 1 << 24)
-    times = {}
-    frames = {}
-    for setting in (1 << 24, k):
-        assert c.overwrite_setting("jump_min_run", setting)
-        for _ in range(2):
-            assert c.compute(), c.last_error()
-        c.timing_reset()
-        for _ in range(4):
-            assert c.compute(), c.last_error()
-        n, ms = c.timing()
-        times[setting] = ms / n
-        frames[setting] = (c.read_image(), c.read_hits(), c.counters())
-    a, b = frames[1 << 24], frames[k]
-    assert a[2] == b[2]
-    assert np.array_equal(a[1], b[1]), f"{int((a[1] != b[1]).any(-1).sum())} pixels differ in hit records"
-    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
-    print(f"\ndepth {depth}, {lights} light(s): {times[1 << 24]:.3f} ms stepping, {times[k]:.3f} ms with jumps (jump_min_run {k})")
-    # (the two times are a printed figure, not an assertion: 4 frames on a shared or clock-ramping GPU are no measurement;
-    # that the jump instance ran is the launch's choice by setting -- tools/jump_ab.py --stats counts its passes)
-
-
-def test_three_casters_in_flight_with_jumps_keep_their_frames():
-    """Three handles (three HIP streams, three jump-table buffers) rendering different sizes of the depth-12 scene at the
-    same time, frame after frame without a host sync in between, closed-form jumps on: every caster's frame stays the
-    frame it renders alone without jumps -- the kernels of different handles share CUs, L2s and XCDs, not tables."""
-    import bench
-    sc = bench.build_scene(12)
-    sizes = [(640, 360), (1920, 1080), (200, 136)]
-    casters, refs = [], []
-    for w, h in sizes:
-        c = bench.make_caster(sc, w, h, 0)
-        assert c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", 1 << 24) and c.compute()
-        refs.append((c.read_image(), c.read_hits()))
-        assert c.overwrite_setting("jump_min_run", 96)
-        casters.append(c)
-    for _ in range(6):
-        for _ in range(5):
-            for c in casters:
-                assert c.compute_async(), c.last_error()
-        for c, (img, hits) in zip(casters, refs):
-            assert c.sync(), c.last_error()
-            assert np.array_equal(c.read_hits(), hits) and np.array_equal(c.read_image().view(np.uint32), img.view(np.uint32))
-
-
-# ------------------------------------------------------------------ device builder for any column scene (SURVEY 8f-4 at scale)
 @pytest.mark.parametrize("depth", [8, 9, 10])
 def test_device_heightfield_builder_equals_the_host_emitter(depth):
     """vrc_build_heightfield on the reference's diamond-square height field (Map::GenerateHeightBitmap, Map.cpp:144-262):
@@ -351,3 +233,104 @@ def test_depth13_diamond_square_terrain_against_the_oracle(atlas):
                                      rows=(y0, y0 + 1), threads=16)
         assert hits_match(c, hits[y0], ohits[y0]), f"row {y0}: {int((hits[y0][..., :7] != ohits[y0][..., :7]).any(-1).sum())} pixels differ"
         assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+
+
+@pytest.mark.parametrize("depth,chunk", [(10, 1 << 20), (12, 64 << 20), (13, 64 << 20)], ids=["d10-1MB-chunks", "d12-3-chunks", "d13-11-chunks"])
+def test_streamed_upload_multi_chunk_against_the_oracle(depth, chunk, tmp_path):
+    """vrc_assign_octree_file with trees that need many staging-buffer cycles (depth 12: 161 MB, depth 13: 674 MB with
+    far pointers) and attachments (mirrors every 64th voxel): sampled rows bit-exact vs the oracle on the in-memory
+    arrays."""
+    sc = bench_scene(depth)
+    dim, w, h = sc["dim"], 1024, 576
+    # (a fresh Octree object over the cached scene's arrays: the materials must not follow the scene into other tests)
+    tree = vrc.Octree(sc["octree"].descriptor_buffer, sc["octree"].root_index, dim).attach_materials_procedural(depth, seed=1, mirror_period=64)
+    path = str(tmp_path / "scene.svo")
+    tree.Save(path)
+    assert os.path.getsize(path) > 2 * chunk
+    c = vrc.CLCaster()
+    assert c.init(0)
+    assert c.add_to_settings_buffer("upload_chunk_bytes", "UPLOAD_CHUNK_BYTES", chunk)
+    assert c.assign_octree_file(path) == dim, c.last_error()
+    os.remove(path)
+    configure(c, dim, sc["atlas"], sc["cam_dir"], sc["cam_pos"], sc["lights"], w, h)
+    assert c.validate() and c.compute(), c.last_error()
+    img, hits = c.read_image(), c.read_hits()
+    assert (hits[..., 3] == 6).sum() > 100                          # mirrors came through the file
+    for y0 in range(5, h, 57):
+        oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=sc["cam_dir"], cam_pos=sc["cam_pos"], lights=c._li, atlas=sc["atlas"],
+                                     tile_dim=(16, 16), descriptors=tree.descriptor_buffer, root_index=tree.root_index, octree_dim=dim,
+                                     using_octree=0, max_distance=3 * dim, rows=(y0, y0 + 1), threads=16,
+                                     attachment_lookup=tree.attachment_lookup, attachments=tree.attachment_buffer)
+        assert hits_match(c, hits[y0], ohits[y0])
+        assert np.array_equal(img[y0].view(np.uint32), oimg[y0].view(np.uint32))
+
+
+@pytest.mark.parametrize("dim,density,seed", [(64, 0.5, 7), (128, 0.02, 5)], ids=["64^3-half-full", "128^3-sparse"])
+def test_strict_reference_buffer_through_both_branches(dim, density, seed, atlas):
+    """The nearest thing to consuming the reference builder's output: a tree in `strict_reference` layout -- the fixed
+    100 000-entry buffer filled from the end (include/map/Octree.h:29), all-ones page-header slots every 0x8000 entries
+    and far pointers (src/map/Octree.cpp:251-315), including the builder's own far-pointer quirks -- rendered through
+    the SVO branch and, with its dense twin, through the array branch; both equal the oracle and each other."""
+    rng = np.random.default_rng(seed)
+    grid = (rng.random(dim ** 3) < density).astype(np.int8) * 5
+    if dim == 64:
+        grid.reshape(dim, dim, dim)[dim // 2 - 2: dim // 2 + 2, :, :] = 0      # a corridor to look along
+    o = vrc.Octree.Generate(grid, dim, buffer_size=100000, strict_reference=True)
+    buf = o.descriptor_buffer
+    assert buf.size == 100000
+    far = int(((buf >> np.uint64(15)) & np.uint64(1))[buf != np.uint64(0xFFFFFFFFFFFFFFFF)].sum())
+    headers = int((buf == np.uint64(0xFFFFFFFFFFFFFFFF)).sum())
+    print(f"\nstrict tree {dim}^3: root at {o.root_index}, {int((buf != 0).sum())} non-zero slots, {far} far pointers, {headers} page headers")
+    assert headers > 0 and (far > 0 or dim == 64)                            # the layout features this test is about
+    # the oracle's builder produces the same array bit for bit (two independent implementations of Octree.cpp)
+    obuf, oroot = orc.octree_generate(grid, dim)
+    assert oroot == o.root_index and np.array_equal(obuf, buf)
+    w, h, md = 160, 120, 3 * dim
+    cam_pos, cam_dir = (dim / 2 + 0.31, 1.37, dim / 2 + 0.43), (1.45, 1.5708)
+    li = np.zeros((1, 10), dtype=np.float32)
+    li[0] = [0.01, 0.01, 0.01, 0.2, dim * 0.8, dim * 0.2, dim * 0.9, 0, 0, -1]
+    frames = []
+    for using_octree in (0, 1):
+        c = make_caster(o, dim, using_octree, cam_dir, cam_pos, li, atlas, w, h, md, grid=grid)
+        assert c.compute(), c.last_error()
+        oimg, ohits, octr = orc.raycast(width=w, height=h, cam_dir=cam_dir, cam_pos=cam_pos, lights=c._li, atlas=atlas, tile_dim=(16, 16),
+                                        descriptors=buf, root_index=o.root_index, octree_dim=dim, using_octree=using_octree,
+                                        grid=grid, max_distance=md)
+        img, hits = c.read_image(), c.read_hits()
+        assert_same(img, hits, c.counters(), oimg, ohits, octr)
+        frames.append((img, hits))
+    assert (frames[0][1][..., 3] == 5).sum() > 1000
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
+    assert np.array_equal(frames[0][1][..., :7], frames[1][1][..., :7])       # (the descriptor-read count differs by construction)
+
+
+def test_a_new_tree_never_inherits_the_old_trees_materials(atlas):
+    """vrc_assign_octree after a tree with attachments: the material buffers of the old tree are gone (they are indexed
+    by the old tree's descriptor indices)."""
+    from test_oracle_cpu import _with_pass_through
+    s = _with_pass_through(scenes.mirror_wall())
+    dim, w, h = s["dim"], 128, 96
+    with_mat = vrc.Octree.Generate(s["grid"], dim).attach_materials_from_grid(s["grid"])
+    t = scenes.random_sparse()
+    tdim = t["dim"]
+    bigger = vrc.Octree.Generate(t["grid"], tdim)                   # another, larger tree without attachments
+    assert bigger.descriptor_buffer.size > with_mat.descriptor_buffer.size
+    li = np.zeros((8, 10), dtype=np.float32)
+    li[:1] = t["lights"]
+    c = vrc.CLCaster()
+    assert c.init(0) and c.assign_octree(with_mat)
+    configure(c, dim, atlas, t["cam_dir"], t["cam_pos"], li, w, h)
+    assert c.validate() and c.compute()
+    assert c.assign_octree(bigger) and c.overwrite_setting("octree_dimensions", tdim) and c.overwrite_setting("max_distance", 3 * tdim)
+    assert c.validate() and c.compute(), c.last_error()
+    oimg, ohits, _ = orc.raycast(width=w, height=h, cam_dir=t["cam_dir"], cam_pos=t["cam_pos"], lights=li, atlas=atlas, tile_dim=(16, 16),
+                                 descriptors=bigger.descriptor_buffer, root_index=bigger.root_index, octree_dim=tdim, using_octree=0,
+                                 max_distance=3 * tdim)
+    assert hits_match(c, c.read_hits(), ohits) and np.array_equal(c.read_image().view(np.uint32), oimg.view(np.uint32))
+    bad = with_mat.attachment_lookup.copy()
+    bad[5] = with_mat.attachment_buffer.size + 3
+    import ctypes as C
+    assert c.assign_octree(with_mat) and c.overwrite_setting("octree_dimensions", dim)
+    rc = vrc.lib.vrc_assign_octree_attachments(c._h, bad.ctypes.data_as(C.POINTER(C.c_uint32)), bad.size,
+                                               with_mat.attachment_buffer.ctypes.data_as(C.POINTER(C.c_uint64)), with_mat.attachment_buffer.size)
+    assert rc == 1 and "past the attachment buffer" in c.last_error()

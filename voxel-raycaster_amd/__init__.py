@@ -65,7 +65,7 @@ class Memory2(C.Structure):
     _fields_ = ([("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in ("device", "rows", "octree_shared", "peer_access", "tree_holders",
                                                                       "coarse_log2", "empty_boxes")]
                 + [(n, C.c_uint64) for n in ("viewport_bytes", "image_bytes", "hit_bytes", "octree_bytes", "coarse_bytes", "box_bytes")]
-                + [("box_build_seconds", C.c_double), ("note", C.c_char * 160)])
+                + [("box_build_seconds", C.c_double), ("note", C.c_char * 160), ("box_queries_cut", C.c_uint64)])
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -115,6 +115,7 @@ SIGNATURES = {
     "vrc_read_hits": (C.c_int, [_H, _i32p, C.c_size_t]),
     "vrc_device_image": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "vrc_get_counters": (C.c_int, [_H, C.POINTER(Counters)]),
+    "vrc_counters_canonical": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "vrc_get_scheduler_stats": (C.c_int, [_H, _u64p]),
     "vrc_timing_reset": (C.c_int, [_H]),
     "vrc_timing_get": (C.c_int, [_H, _u64p, C.POINTER(C.c_double)]),
@@ -721,7 +722,10 @@ class CLCaster:
             raise VrcError(self.last_error())
         d = c.as_dict()
         # descriptor_reads (and field 7 of the hit records) is SURVEY 8d's canonical count unless the frame used the empty boxes
-        d["canonical_reads"] = not self.used_empty_boxes()
+        canonical = C.c_int32(-1)
+        if lib.vrc_counters_canonical(self._h, C.byref(canonical)) != 0:
+            raise RuntimeError(self.last_error())
+        d["canonical_reads"] = bool(canonical.value)
         return d
 
     def scheduler_stats(self) -> dict:

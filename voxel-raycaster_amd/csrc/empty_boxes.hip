@@ -96,6 +96,9 @@ __device__ __forceinline__ unsigned overlap_mask(int ox, int oy, int oz, int hal
 // The search starts at the deepest ANCESTOR of the asking node whose cube holds the whole region (path[level] = the entry of the
 // ancestor at that level, (px, py, pz) a voxel of the node): a slab next to a small node near a surface lies within the node's
 // parent or grandparent, and a walk from the root would spend ten dependent loads on getting there (the depth-12 build: 1.52 -> 1.12 s).
+// region queries of the last box_grow_kernel launch on this device that gave up at their budget (below)
+__device__ unsigned long long g_box_queries_cut;
+
 __device__ bool region_is_empty(const uint64_t *__restrict__ descriptors, const uint64_t *path, int path_levels, int px, int py, int pz,
                                 int n, const int lo[3], const int hi[3]) {
     // the node on top of the stack lives in registers (entry, children still to look at, origin); what is pushed when the search
@@ -116,7 +119,9 @@ __device__ bool region_is_empty(const uint64_t *__restrict__ descriptors, const 
 #ifndef VRC_BOX_QUERY_BUDGET
 #define VRC_BOX_QUERY_BUDGET 4096
 #endif
-    // (a query gives up -- "not empty", the side stops growing -- after this many descents: a bound on what one thread can cost)
+    // (a query gives up -- "not empty", the side stops growing -- after this many descents: a bound on what one thread can cost.
+    // Correct -- any empty box is a correct box -- but the box is then smaller than it could be: g_box_queries_cut counts how
+    // often, vrc_memory_usage2 reports it)
     int budget = VRC_BOX_QUERY_BUDGET;
     for (;;) {
         if (!todo) {
@@ -133,7 +138,7 @@ __device__ bool region_is_empty(const uint64_t *__restrict__ descriptors, const 
         todo &= todo - 1u;
         const int half = 1 << (n - level - 1);
         if ((((unsigned)e >> 8) & (1u << k)) || half == 1) return false;      // a solid leaf / voxel that meets the region
-        if (--budget < 0) return false;
+        if (--budget < 0) { atomicAdd(&g_box_queries_cut, 1ULL); return false; }
         const uint64_t child = (e >> 16) + (uint64_t)(__popc((unsigned)e & 0xffu & ((2u << k) - 1u)) - 1);
         const uint64_t ce = bx_entry(descriptors, child, descriptors[child]);
         const int cx = ox + ((k & 1) ? half : 0), cy = oy + ((k & 2) ? half : 0), cz = oz + ((k & 4) ? half : 0);
@@ -386,6 +391,11 @@ hipError_t launch_box_build(const uint64_t *descriptors, uint64_t n_desc, uint64
     tick("positions", t0);
     const unsigned tb = 256;
     const uint64_t threads = n_desc * 8;
+    {
+        static const unsigned long long zero = 0;
+        e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_box_queries_cut), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(box_grow_kernel, dim3((unsigned)((threads + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, n_desc, root_index, n, pos_tmp, boxes);
     tick("grow", t0);
     if (aux && lc >= 1) {
@@ -394,6 +404,11 @@ hipError_t launch_box_build(const uint64_t *descriptors, uint64_t n_desc, uint64
         tick("table words", t0);
     }
     return hipGetLastError();
+}
+
+// region queries of the last launch_box_build on the current device that gave up at their budget (call after the stream is drained)
+hipError_t box_queries_cut(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_box_queries_cut), sizeof(*out));
 }
 
 hipError_t launch_box_check_cells(const uint64_t *descriptors, uint64_t root_index, int n, int lc, const uint32_t *aux, uint64_t samples,

@@ -177,6 +177,8 @@ template <bool kJump, bool kMulti, bool kTuned, bool kLdsTab = false, bool kCoar
 #endif
 __global__ __launch_bounds__(kBlockThreads, kJump ? (kMulti ? VRC_MIN_BLOCKS_JUMP_MULTI : VRC_MIN_BLOCKS_JUMP) : VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
     static_assert(kJump || !kLdsTab, "tables exist for the jump instances only");
+    static_assert(kCoarse || !kJump, "the jump instances read the tree's top from the coarse table (no table: depth < 5 or coarse_log2 = 0, where jumps never pay)");
+    static_assert(kTuned || kMulti, "the instances with run-time scheduling knobs exist once, with the multi-light code compiled in (it renders one light too)");
     static_assert(kCoarse || !kBox, "the boxes hang on the coarse table's cells");
     extern __shared__ uint64_t lds_stack[];               // [level-1][thread], levels 1..n-1  (kCoarse: [level-lc][thread], levels lc..n-1)
     __shared__ unsigned long long block_ctr[kCtrCount];
@@ -1001,7 +1003,7 @@ constexpr size_t kLdsTabBytes = (size_t)(3 * VRC_LDS_RING) * kBlockThreads * siz
 // per CU its registers allow (VRC_MIN_BLOCKS_JUMP) -- asked of the runtime once per LDS size; setting jump_tables_lds = 0 / 1
 // overrides (2 = this rule).  vrc_api.cpp asks the same question to know whether the global table buffer is needed.
 bool jump_tables_in_lds(const RaycastParams &p) {
-    if (!p.svo || p.stepping_mode != 0) return false;
+    if (!p.svo || p.stepping_mode != 0 || !svo_uses_coarse(p)) return false;
     if (p.jump_tables_lds == 0) return false;
     if (p.jump_tables_lds == 1) return true;
     const size_t lds = svo_stack_bytes(p) + kLdsTabBytes;
@@ -1019,10 +1021,8 @@ bool jump_tables_in_lds(const RaycastParams &p) {
     if (cached_key[slot] != key) {
         const void *fn = box ? (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, true, true, true>)
                                       : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, true, true>))
-                       : coarse ? (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, true, true>)
-                                         : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, true>))
-                                : (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, true, false>)
-                                         : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, false>));
+                             : (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, true, true>)
+                                      : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, true>));
         int per_cu = 0;
         const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlockThreads, lds);
         (void)hipGetLastError();
@@ -1046,9 +1046,14 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
                            p.shade_threshold == kDefaultShadeThreshold && p.safe_steps == (jump ? kDefaultSafeStepsJump : kDefaultSafeSteps) &&
                            p.exact_steps == kDefaultExactSteps && p.burst_steps == kDefaultBurstSteps;
         if (jump && !lds_tab && (!p.jump_cache || !p.jump_slots || p.jump_slot_count < 1)) return hipErrorInvalidValue;
+        // 21 instances: the knobs at their defaults (kTuned) x {no jumps | Euclid tables in global memory | in LDS} x {no table | coarse
+        // table | + empty boxes} x {one light | multi-light}, jumps only with the table; and the same with run-time knobs ONCE each,
+        // with the multi-light code compiled in (it renders a single light too -- the relight block never runs): those exist for the
+        // tests and tools that move the knobs, and a frame rendered through them is the same frame
 #define VRC_LAUNCH(...) hipLaunchKernelGGL((raycast_svo_kernel<__VA_ARGS__>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p)
-#define VRC_LAUNCH_MT(J, L, ...) do { if (multi && tuned) VRC_LAUNCH(J, true, true, L, __VA_ARGS__); else if (multi) VRC_LAUNCH(J, true, false, L, __VA_ARGS__); \
-                                    else if (tuned) VRC_LAUNCH(J, false, true, L, __VA_ARGS__); else VRC_LAUNCH(J, false, false, L, __VA_ARGS__); } while (0)
+#define VRC_LAUNCH_MT(J, L, ...) do { if (!tuned) VRC_LAUNCH(J, true, false, L, __VA_ARGS__); else if (multi) VRC_LAUNCH(J, true, true, L, __VA_ARGS__); \
+                                    else VRC_LAUNCH(J, false, true, L, __VA_ARGS__); } while (0)
+        if (jump && !svo_uses_coarse(p)) return hipErrorInvalidValue;     // (vrc_api.cpp switches the jumps off where there is no table)
         if (svo_uses_boxes(p)) {
             if (lds_tab) VRC_LAUNCH_MT(true, true, true, true);
             else if (jump) VRC_LAUNCH_MT(true, false, true, true);
@@ -1058,9 +1063,7 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
             else if (jump) VRC_LAUNCH_MT(true, false, true);
             else VRC_LAUNCH_MT(false, false, true);
         } else {
-            if (lds_tab) VRC_LAUNCH_MT(true, true, false);
-            else if (jump) VRC_LAUNCH_MT(true, false, false);
-            else VRC_LAUNCH_MT(false, false, false);
+            VRC_LAUNCH_MT(false, false, false);
         }
 #undef VRC_LAUNCH_MT
 #undef VRC_LAUNCH

@@ -30,6 +30,7 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream);
 bool jump_tables_in_lds(const RaycastParams &p);
 hipError_t launch_coarse_build(const uint64_t *descriptors, uint64_t root_index, int log2_dim, int lc, uint64_t *out, hipStream_t stream);
 hipError_t launch_box_positions(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, uint64_t *pos, hipStream_t stream);
+hipError_t box_queries_cut(unsigned long long *out);
 hipError_t launch_box_build(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, int lc, uint64_t *pos_tmp,
                             uint32_t *boxes, uint32_t *aux, hipStream_t stream);
 hipError_t launch_box_check_cells(const uint64_t *descriptors, uint64_t root_index, int n, int lc, const uint32_t *aux, uint64_t samples,
@@ -68,6 +69,7 @@ struct vrc_tree {
     std::mutex guard;
     uint64_t *d_coarse = nullptr; uint64_t coarse_root = 0; int coarse_depth = 0, coarse_log2 = 0;
     uint32_t *d_boxes = nullptr, *d_box_aux = nullptr; uint64_t box_root = 0; int box_depth = 0, box_log2 = 0; double box_build_seconds = 0.0;
+    unsigned long long box_queries_cut = 0;               // region queries of the build that gave up at their budget (boxes smaller than they could be)
     // an allocation failed: the frames go on without the structure.  Not retried every frame -- but retried as soon as what was
     // asked for changes (level, root, depth) or the host sets coarse_log2 / empty_boxes again (vrc_setting_add / _set)
     bool coarse_gave_up = false, boxes_gave_up = false;
@@ -1091,6 +1093,7 @@ void derive_from_tree(vrc_caster *h, vrc_tree *t, int log2_dim, uint64_t root_in
                 if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
                 if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+                if (e == hipSuccess && vrc::box_queries_cut(&t->box_queries_cut) != hipSuccess) { (void)hipGetLastError(); t->box_queries_cut = 0; }
                 if (e0) (void)hipEventDestroy(e0);
                 if (e1) (void)hipEventDestroy(e1);
                 if (pos_tmp) (void)hipFree(pos_tmp);
@@ -1252,7 +1255,8 @@ int compute_async_one(vrc_caster *h) {
     p.jump_tables_lds = (int32_t)std::min<int64_t>(2, std::max<int64_t>(0, setting_or(h, "jump_tables_lds", 2)));
     const bool tables_in_lds = vrc::jump_tables_in_lds(p);
     p.jump_tables_lds = tables_in_lds ? 1 : 0;                     // resolved once, here: the launch takes it as it is
-    p.jump_min_run = (int32_t)std::min<int64_t>(vrc::kJumpOff, std::max<int64_t>(1, setting_or(h, "jump_min_run",
+    // (the jump instances read the tree's top from the coarse table: without one -- depth < 5, coarse_log2 = 0 -- there are no jumps)
+    p.jump_min_run = !p.coarse ? vrc::kJumpOff : (int32_t)std::min<int64_t>(vrc::kJumpOff, std::max<int64_t>(1, setting_or(h, "jump_min_run",
                                     p.log2_dim >= (p.boxes ? vrc::kDefaultJumpMinDepthBoxes : vrc::kDefaultJumpMinDepth) ? (tables_in_lds ? vrc::kDefaultJumpMinRunLds : vrc::kDefaultJumpMinRun)
                                                                             : vrc::kJumpOff)));
     p.safe_steps = (int32_t)std::min<int64_t>(256, std::max<int64_t>(2, setting_or(h, "safe_steps",
@@ -1461,6 +1465,7 @@ int vrc_memory_usage2(vrc_caster *h, int32_t rank, vrc_memory2 *out) {
         m.box_bytes = (t->d_boxes ? (uint64_t)sizeof(uint32_t) * 8 * t->n_desc : 0) + (t->d_box_aux ? (uint64_t)sizeof(uint32_t) << (3 * t->box_log2) : 0);
         m.box_build_seconds = t->box_build_seconds;
         snprintf(m.note, sizeof(m.note), "%s%s", t->coarse_note.c_str(), t->box_note.c_str());
+        m.box_queries_cut = t->d_boxes ? t->box_queries_cut : 0;
     }
     const uint32_t n = std::min<uint32_t>(out->struct_size, (uint32_t)sizeof(m));
     m.struct_size = n;
@@ -1526,6 +1531,14 @@ int vrc_get_counters(vrc_caster *h, vrc_counters *out) {
     if (out->watchdog_trips)
         return fail(h, VRC_ERR_DEVICE, "the kernel's round watchdog stopped %llu wavefronts: the frame is invalid",
                     (unsigned long long)out->watchdog_trips);
+    return VRC_OK;
+}
+
+int vrc_counters_canonical(vrc_caster *h, int32_t *canonical) {
+    if (!h || !canonical) return VRC_ERR_INVALID_ARGUMENT;
+    bool boxes = h->last_frame_boxes;
+    for (const vrc_caster *q : h->peers) boxes = boxes || q->last_frame_boxes;
+    *canonical = boxes ? 0 : 1;
     return VRC_OK;
 }
 
