@@ -163,6 +163,12 @@ int vrc_assign_lights(vrc_caster *h, const float *packed, const int32_t *light_c
  *     the levels of the tree above level k as a dense table in HBM, built on the device from the descriptor array at the first
  *     vrc_compute after a tree is assigned (8 << 3k bytes: 1 GB at k = 9).  Both SVO kernels read it instead of descending
  *     from the root; frames, hit records and the exact mode's counters are the same with and without it
+ *   empty_boxes (-1: by the tree's size; 0: never -- the canonical traversal, canonical read counts; 1: a box word per descriptor and
+ *     child, trees below 2^31 descriptors; 2: box records for the upper levels only -- any tree): an empty node is widened to the
+ *     empty box a device-side pass over the descriptor array found around it (vrc_prepare builds the words); frames and hit
+ *     records unchanged but for the read count (vrc_counters_canonical).  By default a word per descriptor up to 2^29 descriptors
+ *     (32 bytes each), beyond that records for as many upper levels as empty_box_records (default 400 M: 36 bytes each, 52 while
+ *     building; at most a quarter of the free device memory) reach; empty_box_levels caps the levels
  *   jump_tables_lds (2: the Euclid tables of the exact closed-form jumps live in LDS when they fit at full occupancy;
  *     1 / 0: always / never)   jump_min_run (closed-form jumps for runs of at least this many iterations; 1 << 24: off)
  * Settings stay live after vrc_validate (overwrite_setting needs no recompile); structural ones are re-checked by
@@ -255,6 +261,8 @@ typedef struct vrc_memory2 {
     char     note[160];               /* why an optional structure is missing (allocation failure), else empty */
     uint64_t box_queries_cut;         /* region queries of the boxes' build that gave up at their budget of 4096 descents: the
                                          boxes next to them are smaller than they could be (never wrong); 0 on every BASELINE scene */
+    uint64_t box_records;             /* descriptors that carry box words: all of them, or those of the upper box_levels levels */
+    int32_t  box_levels, reserved_;   /* levels of the tree (from the root) whose descriptors have box records */
 } vrc_memory2;
 int vrc_memory_usage2(vrc_caster *h, int32_t rank, vrc_memory2 *out);
 

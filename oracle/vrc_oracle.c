@@ -632,7 +632,7 @@ static void raycast_pixel(const orc_scene *s, int px, int py, const int32_t bias
         const desc_src src = scene_src(s);
         svo_init(&cur, &src, (uint64_t)s->octree_root_index, (int)s->octree_dimensions);
         if (jump) {                                   /* the product's rule (vrc_params.h coarse_level_for_depth), restated */
-            int L = s->coarse_log2 < 0 ? (cur.n >= 16 ? 10 : cur.n >= 5 ? (cur.n - 2 < 9 ? cur.n - 2 : 9) : 0) : s->coarse_log2;
+            int L = s->coarse_log2 < 0 ? (cur.n >= 14 ? 10 : cur.n >= 5 ? (cur.n - 2 < 9 ? cur.n - 2 : 9) : 0) : s->coarse_log2;
             /* round 5 (vrc_api.cpp): by default no table of more than 16 x the descriptor array's bytes, unless it is below 1 MiB */
             while (s->coarse_log2 < 0 && L >= 1 && (8ULL << (3 * L)) > 16ULL * 8ULL * s->n_descriptors && (8ULL << (3 * L)) > (1ULL << 20)) L--;
             if (L > cur.n - 2) L = cur.n - 2;

@@ -160,3 +160,46 @@ def test_every_voxel_of_every_box_is_empty_on_the_host(make, atlas):
     assert n_boxes > 20 and grown > n_boxes // 4
     print(f"\n{s['name']}: {n_boxes} empty child slots, {grown} of them widened; mean box volume {volume / n_boxes:.0f} voxels "
           f"({volume / node_volume:.1f} x the nodes')")
+
+
+@pytest.mark.parametrize("depth,lights,w,h", [(8, 1, 640, 360), (10, 2, 640, 360), (12, 1, 1280, 720), (13, 1, 960, 540)], ids=["d8", "d10-2lights", "d12", "d13"])
+def test_boxes_for_the_upper_levels_only_never_change_the_frame(depth, lights, w, h):
+    """Round 6 (the limit lifted is include/map/Octree.h:29 -- the reference stops at 100 000 descriptors, round 5's
+    boxes at 2^28): box records for the descriptors of the tree's upper levels only (setting empty_boxes = 2), numbered breadth-first,
+    the record id carried down the traversal stack, nodes below the record levels widened over their empty siblings.  Whatever the number
+    of levels -- one (the root alone), a few, all -- with and without the closed-form jumps: the image and the hit records of the
+    canonical traversal (read count aside), the same counters; the self-check finds no solid voxel in a sampled box."""
+    import bench
+    sc = bench.build_scene(depth)
+    c = bench.make_caster(sc, w, h, 0, light_count=lights)
+    assert c.add_to_settings_buffer("empty_boxes", "EMPTY_BOXES", 0)
+    ref = _frame(c)
+    assert ref[2]["canonical_reads"]
+    full = None
+    assert c.add_to_settings_buffer("empty_box_levels", "EMPTY_BOX_LEVELS", 0)
+    for levels in (1, 2, depth - 4, depth - 2, 0):
+        assert c.overwrite_setting("empty_boxes", 2) and c.overwrite_setting("empty_box_levels", levels)
+        for jmr in ((1 << 24, 16) if depth >= 11 else (1 << 24,)):
+            assert c.overwrite_setting("jump_min_run", jmr) or c.add_to_settings_buffer("jump_min_run", "JUMP_MIN_RUN", jmr)
+            img, hits, ctr = _frame(c)
+            m = c.memory_usage2()
+            tag = f"empty_box_levels={levels} jump_min_run={jmr}: {m['box_levels']} levels, {m['box_records']} records"
+            assert c.used_empty_boxes() and not ctr["canonical_reads"] and m["box_records"] > 0, tag
+            assert (m["box_levels"] == levels) if levels else (1 <= m["box_levels"] <= depth), tag
+            assert np.array_equal(img, ref[0]), f"{tag}: {int((img != ref[0]).any(-1).sum())} pixels differ"
+            assert np.array_equal(hits[..., :7], ref[1][..., :7]), f"{tag}: {int((hits[..., :7] != ref[1][..., :7]).any(-1).sum())} hit records differ"
+            assert _but_reads(ctr) == _but_reads(ref[2]), tag
+        chk = c.empty_boxes_check(1 << 20, seed=depth + levels)
+        assert chk["solid_voxels"] == 0 and chk["boxes_sampled"] > 0, (levels, chk)
+        if levels == 0:
+            full = (m["box_records"], m["box_levels"], ctr["descriptor_reads"])
+    # the records with all levels: as many reads as ... at most the canonical traversal's, and fewer records than descriptors x 1
+    assert full[0] <= sc["octree"].descriptor_buffer.size + 8 and full[2] <= ref[2]["descriptor_reads"]
+    with pytest.raises(Exception):
+        c.read_empty_boxes(0, 1)                                    # (records of the upper levels are not indexed by descriptor)
+    # back to a word per descriptor on the same tree
+    assert c.overwrite_setting("empty_boxes", 1) and c.overwrite_setting("jump_min_run", 1 << 24 if depth < 11 else 16)
+    img, hits, ctr = _frame(c)
+    assert np.array_equal(img, ref[0]) and np.array_equal(hits[..., :7], ref[1][..., :7]) and c.memory_usage2()["box_levels"] == depth
+    print(f"\ndepth {depth}: reads canonical {ref[2]['descriptor_reads'] / 1e6:.2f} M, upper-level records (all levels) {full[2] / 1e6:.2f} M "
+          f"({full[0]} records, {full[1]} levels), a word per descriptor {ctr['descriptor_reads'] / 1e6:.2f} M")

@@ -48,8 +48,10 @@ def kernels():
 
 
 def svo(jump, multi, tuned, lds, coarse, box=False):
+    """lds: rows of the Euclid-table ring in LDS (True = 3), 0 / False = tables in global memory."""
     b = lambda v: "Lb1E" if v else "Lb0E"
-    return "_ZN3vrc18raycast_svo_kernelI" + b(jump) + b(multi) + b(tuned) + b(lds) + b(coarse) + b(box) + "EEvNS_13RaycastParamsE"
+    rows = 3 if lds is True else int(lds)
+    return "_ZN3vrc18raycast_svo_kernelI" + b(jump) + b(multi) + b(tuned) + f"Li{rows}E" + b(coarse) + b(box) + "EEvNS_13RaycastParamsE"
 
 
 def test_headline_instance_budget(kernels):
@@ -91,20 +93,21 @@ def test_no_spill_in_the_hot_phases():
     if not os.path.exists(spill_map.g.HIPCC):
         pytest.skip("no hipcc in this image")
     text = spill_map.assembly()
-    for inst in ("ILb1ELb0ELb1ELb1ELb1ELb1E", "ILb1ELb1ELb1ELb1ELb1ELb1E", "ILb1ELb0ELb1ELb1ELb1ELb0E", "ILb1ELb1ELb1ELb1ELb1ELb0E"):
+    for inst in ("ILb1ELb0ELb1ELi3ELb1ELb1E", "ILb1ELb1ELb1ELi3ELb1ELb1E", "ILb1ELb0ELb1ELi3ELb1ELb0E", "ILb1ELb1ELb1ELi3ELb1ELb0E", "ILb1ELb0ELb1ELi2ELb1ELb1E", "ILb1ELb1ELb1ELi2ELb1ELb1E"):
         rows = spill_map.spill_map(text, inst)
         assert rows is not None and "event_begin" in rows and "jump_block_begin" in rows, inst
         hot = {ph: r[:2] for ph, r in rows.items() if ph in spill_map.HOT_PHASES and (r[0] or r[1])}
         assert not hot, f"raycast_svo_kernel<{inst}>: scratch instructions in hot phases {hot}"
-    single = spill_map.spill_map(text, "ILb1ELb0ELb1ELb1ELb1ELb1E")
+    single = spill_map.spill_map(text, "ILb1ELb0ELb1ELi3ELb1ELb1E")
     assert sum(r[0] + r[1] for r in single.values()) == 0           # the headline instance: no spill anywhere
 
 
 def test_every_svo_instance_keeps_its_occupancy(kernels):
     names = [n for n in kernels if n.startswith("_ZN3vrc18raycast_svo_kernelI")]
-    # 36 -> 21.  Knobs at their defaults: {no jumps | tables in global memory | in LDS} x {no table | coarse | + boxes}
-    # x {one light | multi-light}, jumps only with the table = 14; run-time knobs: the same 7 once, multi-light code compiled in
-    assert len(names) == 21
+    # 36 -> 24.  Knobs at their defaults: {no jumps | tables in global memory | 3 rows in LDS} x {no table | coarse |
+    # + boxes} x {one light | multi-light}, jumps only with the table = 14, + the box instances with a 2-row ring (deep trees) = 16;
+    # run-time knobs: the same 8 once, multi-light code compiled in
+    assert len(names) == 24
     for n in names:
         jump = n[len("_ZN3vrc18raycast_svo_kernelI"):].startswith("Lb1E")
         assert kernels[n]["vgpr_count"] <= (96 if jump else 80), n

@@ -3,7 +3,7 @@
 raycast_kernel.hip), from the gfx950 assembly (cross-compiles, no GPU).  A spill costs where it is EXECUTED: one in the event phase
 runs ~28 times per wave, one in the hit block twice, one in the prologue once -- the byte size of the scratch segment says nothing
 about that (round 6: the multi-light instance went from 3.66 to 3.19 ms while its segment GREW from 84 to 100 bytes).
-python tools/spill_map.py [instance-substring ...]   e.g.  ILb1ELb1ELb1ELb1ELb1ELb1E   (default: the two headline instances)
+python tools/spill_map.py [instance-substring ...]   e.g.  ILb1ELb1ELb1ELi3ELb1ELb1E = <true, true, true, 3, true, true>   (default: the two headline instances)
 VRC_EXTRA_FLAGS="-D..." adds compiler flags.  tests/test_kernel_resources.py asserts that the hot phases hold none."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,7 +42,7 @@ def spill_map(text, instance):
 
 
 if __name__ == "__main__":
-    want = sys.argv[1:] or ["ILb1ELb0ELb1ELb1ELb1ELb1E", "ILb1ELb1ELb1ELb1ELb1ELb1E"]
+    want = sys.argv[1:] or ["ILb1ELb0ELb1ELi3ELb1ELb1E", "ILb1ELb1ELb1ELi3ELb1ELb1E"]
     text = assembly([a for a in os.environ.get("VRC_EXTRA_FLAGS", "").split() if a])
     for w in want:
         rows = spill_map(text, w)

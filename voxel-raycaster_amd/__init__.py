@@ -65,7 +65,8 @@ class Memory2(C.Structure):
     _fields_ = ([("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in ("device", "rows", "octree_shared", "peer_access", "tree_holders",
                                                                       "coarse_log2", "empty_boxes")]
                 + [(n, C.c_uint64) for n in ("viewport_bytes", "image_bytes", "hit_bytes", "octree_bytes", "coarse_bytes", "box_bytes")]
-                + [("box_build_seconds", C.c_double), ("note", C.c_char * 160), ("box_queries_cut", C.c_uint64)])
+                + [("box_build_seconds", C.c_double), ("note", C.c_char * 160), ("box_queries_cut", C.c_uint64),
+                   ("box_records", C.c_uint64), ("box_levels", C.c_int32), ("reserved_", C.c_int32)])
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}

@@ -208,13 +208,16 @@ __device__ uint32_t grow_box(const uint64_t *__restrict__ descriptors, const uin
     return word;
 }
 
-__global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64_t n_desc, uint64_t root_index, int n,
-                                const uint64_t *__restrict__ pos, uint32_t *__restrict__ boxes) {
+// (desc_of == nullptr: one box record per descriptor, record i = descriptor i; else record i belongs to descriptor desc_of[i] -- the
+// upper levels only, see launch_box_build_upper)
+__global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64_t n_records, uint64_t root_index, int n,
+                                const uint64_t *__restrict__ pos, const uint64_t *__restrict__ desc_of, uint32_t *__restrict__ boxes) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t idx = t >> 3;
+    const uint64_t rec = t >> 3;
     const int k = (int)(t & 7u);
-    if (idx >= n_desc) return;
-    const uint64_t ps = pos[idx];
+    if (rec >= n_records) return;
+    const uint64_t idx = desc_of ? desc_of[rec] : rec;
+    const uint64_t ps = idx == kPosNone ? kPosNone : pos[rec];
     uint32_t word = 0;
     if (ps != kPosNone) {
         const unsigned valid = (unsigned)(descriptors[idx] >> 16) & 0xffu;
@@ -238,24 +241,28 @@ __global__ void box_grow_kernel(const uint64_t *__restrict__ descriptors, uint64
 }
 
 // the coarse table's parallel word (see the header comment); same descent as coarse_build_kernel (raycast_jump_kernel.hip)
+// (box_child == nullptr: box records are indexed by descriptor; else by the record ids of launch_box_build_upper, which exist for the
+// descriptors of the levels below box_levels: a cell that resolves at a deeper level gets 0 -- the node itself, no widening)
 __global__ void box_aux_kernel(const uint64_t *__restrict__ descriptors, uint64_t root_index, int n, int lc,
-                               const uint32_t *__restrict__ boxes, uint32_t *__restrict__ aux) {
+                               const uint32_t *__restrict__ boxes, const uint32_t *__restrict__ box_child, int box_levels, uint32_t *__restrict__ aux) {
     const uint64_t cell = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;     // x fastest
     if (cell >> (3 * lc)) return;
     const int sh = n - lc;
     const int x = (int)((cell & ((1u << lc) - 1u)) << sh), y = (int)(((cell >> lc) & ((1u << lc) - 1u)) << sh), z = (int)((cell >> (2 * lc)) << sh);
-    uint64_t own = root_index;
+    uint64_t own = root_index, rec = box_child ? 0 : root_index;     // the descriptor, and its box record
     uint64_t cur = bx_entry(descriptors, root_index, descriptors[root_index]);
     int top = 0;
     uint32_t out = 0;
     for (;;) {
-        if (top == lc) { out = (uint32_t)own; break; }
+        if (top == lc) { out = top < box_levels ? (uint32_t)rec : 0u; break; }
         const int b = n - top - 1;
         const int i = ((x >> b) & 1) | (((y >> b) & 1) << 1) | (((z >> b) & 1) << 2);
         const unsigned masks = (unsigned)cur & 0xffffu, bit = 1u << i;
-        if (!(masks & bit)) { out = boxes[own * 8 + (uint64_t)i]; break; }     // empty above the table's level: its box
+        if (!(masks & bit)) { out = top < box_levels ? boxes[rec * 8 + (uint64_t)i] : 0u; break; }   // empty above the table's level: its box
         if ((masks >> 8) & bit) { out = 0; break; }                             // solid leaf
-        own = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
+        const unsigned rank = (unsigned)__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1u;
+        own = (cur >> 16) + (uint64_t)rank;
+        rec = box_child ? (top + 1 < box_levels ? (uint64_t)box_child[rec] + rank : 0) : own;
         cur = bx_entry(descriptors, own, descriptors[own]);
         top++;
     }
@@ -270,15 +277,17 @@ __device__ __forceinline__ uint64_t bx_mix(uint64_t x) {
     return x ^ (x >> 31);
 }
 __global__ void box_check_kernel(const uint64_t *__restrict__ descriptors, uint64_t n_desc, uint64_t root_index, int n,
-                                 const uint64_t *__restrict__ pos, const uint32_t *__restrict__ boxes, uint64_t samples, uint64_t seed,
-                                 unsigned long long *__restrict__ result) {
+                                 const uint64_t *__restrict__ pos, const uint64_t *__restrict__ desc_of, const uint32_t *__restrict__ boxes,
+                                 uint64_t samples, uint64_t seed, unsigned long long *__restrict__ result) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= samples) return;
     // a (descriptor, child) pair per sample; pairs that are no empty child slot are skipped
     const uint64_t r0 = bx_mix(seed ^ t), r1 = bx_mix(r0), r2 = bx_mix(r1);
-    const uint64_t idx = r0 % n_desc;
+    const uint64_t rec = r0 % n_desc;                     // (n_desc: the number of box records)
     const int k = (int)(r1 & 7u);
-    const uint64_t ps = pos[idx];
+    const uint64_t idx = desc_of ? desc_of[rec] : rec;
+    if (idx == kPosNone) return;
+    const uint64_t ps = pos[rec];
     if (ps == kPosNone) return;
     const unsigned valid = (unsigned)(descriptors[idx] >> 16) & 0xffu;
     if (valid & (1u << k)) return;
@@ -287,7 +296,7 @@ __global__ void box_check_kernel(const uint64_t *__restrict__ descriptors, uint6
     lo[0] = (int)(ps & ((1u << kPosBits) - 1u)) + ((k & 1) ? s : 0);
     lo[1] = (int)((ps >> kPosBits) & ((1u << kPosBits) - 1u)) + ((k & 2) ? s : 0);
     lo[2] = (int)((ps >> (2 * kPosBits)) & ((1u << kPosBits) - 1u)) + ((k & 4) ? s : 0);
-    const uint32_t w = boxes[idx * 8 + (uint64_t)k];
+    const uint32_t w = boxes[rec * 8 + (uint64_t)k];
     for (int a = 0; a < 3; a++) {
         hi[a] = lo[a] + s + (box_decode((w >> (15 + 5 * a)) & 31u) << b);
         lo[a] -= box_decode((w >> (5 * a)) & 31u) << b;
@@ -358,6 +367,55 @@ __global__ void box_check_cells_kernel(const uint64_t *__restrict__ descriptors,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Boxes for the UPPER LEVELS only (round 6): trees beyond ~2^29 descriptors cannot afford 32 bytes per descriptor -- and should not:
+// a box word gathered from a 45 GB array misses the TLB as well as the caches (the depth-15 bench terrain, 1.4 G descriptors: 4.8 ms
+// with all words against 3.75 without any).  A breadth-first sweep from the root numbers the descriptors of the levels 0 .. L-1 -- L the
+// deepest level the record budget reaches -- and only they get box words: record r holds desc[r] (descriptor index), pos[r] and
+// child[r], the record of the descriptor's first child (the children of one descriptor are consecutive, in the descriptor array's
+// own order: child slot k's record is child[r] + popcount(valid below k), like the descriptor index itself).  The kernel carries the
+// record id down its traversal stack in place of the descriptor index; below level L an empty node is widened over its empty
+// siblings as in the box-less kernels.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void box_bfs_count_kernel(const uint64_t *__restrict__ descriptors, const uint64_t *__restrict__ desc_of, uint64_t first, uint64_t count,
+                                     unsigned long long *__restrict__ total) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned nv = 0;
+    if (t < count) {
+        const uint64_t idx = desc_of[first + t];
+        if (idx != kPosNone) nv = (unsigned)__popc((unsigned)(descriptors[idx] >> 16) & 0xffu);
+    }
+    for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o);
+    if ((threadIdx.x & 63) == 0 && nv) atomicAdd(total, (unsigned long long)nv);
+}
+__global__ void box_bfs_emit_kernel(const uint64_t *__restrict__ descriptors, int n, int level, uint64_t first, uint64_t count,
+                                    uint64_t *__restrict__ desc_of, uint64_t *__restrict__ pos, uint32_t *__restrict__ child,
+                                    unsigned long long *__restrict__ next_free) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t rec = first + t, idx = desc_of[rec];
+    child[rec] = 0;
+    if (idx == kPosNone) return;
+    const uint64_t e = bx_entry(descriptors, idx, descriptors[idx]);
+    const unsigned valid = (unsigned)e & 0xffu, leaf = ((unsigned)e >> 8) & 0xffu;
+    const unsigned nv = (unsigned)__popc(valid);
+    if (!nv) return;
+    const uint64_t base = atomicAdd(next_free, (unsigned long long)nv);
+    child[rec] = (uint32_t)base;
+    const uint64_t ps = pos[rec];
+    const int half = 1 << (n - level - 1);
+    const int x = (int)(ps & ((1u << kPosBits) - 1u)), y = (int)((ps >> kPosBits) & ((1u << kPosBits) - 1u)), z = (int)((ps >> (2 * kPosBits)) & ((1u << kPosBits) - 1u));
+    unsigned rank = 0;
+    for (int k = 0; k < 8; k++) {
+        if (!(valid & (1u << k))) continue;
+        const bool has_record = !(leaf & (1u << k)) && half > 1;   // a kept child with a descriptor of its own
+        desc_of[base + rank] = has_record ? (e >> 16) + rank : kPosNone;
+        pos[base + rank] = pack_pos(x + ((k & 1) ? half : 0), y + ((k & 2) ? half : 0), z + ((k & 4) ? half : 0), level + 1);
+        rank++;
+    }
+}
+
 }  // namespace
 
 // pos[n_desc]: position and level of every descriptor the root reaches (kPosNone for far-pointer slots, page headers, unused slots)
@@ -396,14 +454,91 @@ hipError_t launch_box_build(const uint64_t *descriptors, uint64_t n_desc, uint64
         e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_box_queries_cut), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(box_grow_kernel, dim3((unsigned)((threads + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, n_desc, root_index, n, pos_tmp, boxes);
+    hipLaunchKernelGGL(box_grow_kernel, dim3((unsigned)((threads + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, n_desc, root_index, n, pos_tmp, (const uint64_t *)nullptr, boxes);
     tick("grow", t0);
     if (aux && lc >= 1) {
         const uint64_t cells = 1ULL << (3 * lc);
-        hipLaunchKernelGGL(box_aux_kernel, dim3((unsigned)((cells + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, root_index, n, lc, boxes, aux);
+        hipLaunchKernelGGL(box_aux_kernel, dim3((unsigned)((cells + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, root_index, n, lc, boxes, (const uint32_t *)nullptr, n, aux);
         tick("table words", t0);
     }
     return hipGetLastError();
+}
+
+// What launch_box_build_upper leaves behind (device memory, the caller frees it): records 0 .. count-1 for the descriptors of the
+// levels 0 .. levels-1.
+struct BoxUpper { uint64_t *desc = nullptr, *pos = nullptr; uint32_t *child = nullptr, *boxes = nullptr; uint64_t count = 0; int levels = 0; };
+
+// max_records: the budget (52 bytes of device memory each while building, 36 after the caller frees desc / pos -- or keeps them for
+// vrc_empty_boxes_check); max_levels: 0 = as many as the budget reaches.  Synchronises the stream (one count per level comes back).
+hipError_t launch_box_build_upper(const uint64_t *descriptors, uint64_t root_index, int n, int lc, uint64_t max_records, int max_levels,
+                                  BoxUpper *out, uint32_t *aux, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n < 2 || n > kPosBits || !out || max_records < 9 || max_records > 0xffffff00ULL) return hipErrorInvalidValue;
+    BoxUpper u;
+    unsigned long long *d_ctr = nullptr;
+    auto fail = [&](hipError_t e) {
+        (void)hipGetLastError();
+        if (u.desc) (void)hipFree(u.desc);
+        if (u.pos) (void)hipFree(u.pos);
+        if (u.child) (void)hipFree(u.child);
+        if (u.boxes) (void)hipFree(u.boxes);
+        if (d_ctr) (void)hipFree(d_ctr);
+        return e;
+    };
+    const unsigned tb = 256;
+    // the level sizes first (count passes only, over two ping-pong id lists would cost as much as the records themselves: the
+    // records are allocated at the budget and trimmed by the count)
+    hipError_t e = hipMalloc((void **)&u.desc, sizeof(uint64_t) * max_records);
+    if (e == hipSuccess) e = hipMalloc((void **)&u.pos, sizeof(uint64_t) * max_records);
+    if (e == hipSuccess) e = hipMalloc((void **)&u.child, sizeof(uint32_t) * max_records);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_ctr, sizeof(unsigned long long));
+    if (e != hipSuccess) return fail(e);
+    const uint64_t root_pos = 0;                                   // pack_pos(0, 0, 0, level 0)
+    e = hipMemcpyAsync(u.desc, &root_index, sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(u.pos, &root_pos, sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);           // (the two sources are locals)
+    if (e != hipSuccess) return fail(e);
+    uint64_t first = 0, count = 1, total = 1;
+    int levels = 1;
+    for (int level = 0; level < n - 1; level++) {
+        if (max_levels > 0 && levels >= max_levels) break;
+        unsigned long long next = 0;
+        e = hipMemsetAsync(d_ctr, 0, sizeof(unsigned long long), stream);
+        if (e != hipSuccess) return fail(e);
+        hipLaunchKernelGGL(box_bfs_count_kernel, dim3((unsigned)((count + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, u.desc, first, count, d_ctr);
+        e = hipMemcpyAsync(&next, d_ctr, sizeof(next), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return fail(e);
+        if (!next || total + next > max_records) break;
+        const unsigned long long start = total;
+        e = hipMemcpyAsync(d_ctr, &start, sizeof(start), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return fail(e);
+        hipLaunchKernelGGL(box_bfs_emit_kernel, dim3((unsigned)((count + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, n, level, first, count,
+                           u.desc, u.pos, u.child, d_ctr);
+        e = hipStreamSynchronize(stream);                           // (`start` is a local; and the next count reads what this wrote)
+        if (e != hipSuccess) return fail(e);
+        first = total; count = next; total += next; levels = level + 2;
+    }
+    // the records of the last level have no children among the records
+    e = hipMemsetAsync(u.child + first, 0, sizeof(uint32_t) * count, stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&u.boxes, sizeof(uint32_t) * 8 * total);
+    if (e != hipSuccess) return fail(e);
+    {
+        static const unsigned long long zero = 0;
+        e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_box_queries_cut), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return fail(e);
+    }
+    hipLaunchKernelGGL(box_grow_kernel, dim3((unsigned)((total * 8 + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, total, root_index, n, u.pos, u.desc, u.boxes);
+    if (aux && lc >= 1) {
+        const uint64_t cells = 1ULL << (3 * lc);
+        hipLaunchKernelGGL(box_aux_kernel, dim3((unsigned)((cells + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, root_index, n, lc, u.boxes, u.child, levels, aux);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(e);
+    (void)hipFree(d_ctr);
+    u.count = total; u.levels = levels;
+    *out = u;
+    return hipSuccess;
 }
 
 // region queries of the last launch_box_build on the current device that gave up at their budget (call after the stream is drained)
@@ -423,14 +558,14 @@ hipError_t launch_box_check_cells(const uint64_t *descriptors, uint64_t root_ind
 }
 
 // result[0] = boxes sampled, result[1] = sampled voxels the tree calls solid (must be 0); `result` is device memory, zeroed here
-hipError_t launch_box_check(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, const uint64_t *pos,
+hipError_t launch_box_check(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, const uint64_t *pos, const uint64_t *desc_of,
                             const uint32_t *boxes, uint64_t samples, uint64_t seed, unsigned long long *result, hipStream_t stream) {
     (void)hipGetLastError();
     hipError_t e = hipMemsetAsync(result, 0, 2 * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
     if (!samples) return hipSuccess;
     const unsigned tb = 256;
-    hipLaunchKernelGGL(box_check_kernel, dim3((unsigned)((samples + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, n_desc, root_index, n, pos, boxes, samples, seed, result);
+    hipLaunchKernelGGL(box_check_kernel, dim3((unsigned)((samples + tb - 1) / tb)), dim3(tb), 0, stream, descriptors, n_desc, root_index, n, pos, desc_of, boxes, samples, seed, result);
     return hipGetLastError();
 }
 

@@ -38,9 +38,6 @@
 #include "raycast_common.hpp"
 #include "safe_run.hpp"
 
-#ifndef VRC_LDS_RING
-#define VRC_LDS_RING 3                // rows of the Euclid-table ring when it lives in LDS (exact_jump.hpp: 3 or 4).  Three 8-byte rows x 3 pairs = 72 bytes per lane: with the 36 bytes of a 3-level stack + index array that stays inside the 128 bytes per lane of 5 blocks per CU; four rows do not
-#endif
 #ifndef VRC_RELIGHT_THRESHOLD
 #define VRC_RELIGHT_THRESHOLD 64      // lanes that must wait for the next light before a wave with stepping lanes serves them
 #endif
@@ -171,11 +168,17 @@ constexpr int kHwRegXccId = (3 << 11) | (0 << 6) | 20;
 //         the descriptor-read counter now counts the reads this traversal makes, not SURVEY 8d's canonical ones (setting
 //         empty_boxes = 0 renders with the canonical counter).  The cursor keeps the INDEX of the descriptor whose masks it holds
 //         in a second LDS array beside the stack ([level - lc][thread], one dword).
-template <bool kJump, bool kMulti, bool kTuned, bool kLdsTab = false, bool kCoarse = false, bool kBox = false>
+template <bool kJump, bool kMulti, bool kTuned, int kLdsRows = 0, bool kCoarse = false, bool kBox = false>
 #ifndef VRC_MIN_BLOCKS_JUMP_MULTI
 #define VRC_MIN_BLOCKS_JUMP_MULTI VRC_MIN_BLOCKS_JUMP
 #endif
 __global__ __launch_bounds__(kBlockThreads, kJump ? (kMulti ? VRC_MIN_BLOCKS_JUMP_MULTI : VRC_MIN_BLOCKS_JUMP) : VRC_MIN_BLOCKS) void raycast_svo_kernel(const RaycastParams p) {
+    // kLdsRows: rows of the Euclid-table ring in LDS (kLdsTab), 0 = the tables live in global memory (ring of 4).  3 rows x 3 pairs x
+    // 8 bytes = 72 bytes per lane beside a stack of up to 4 levels with the boxes' index array (6 without) inside the 128 bytes a lane
+    // has at 5 blocks per CU; 2 rows = 48 bytes for the deeper stacks of trees from depth 15 on WITH boxes (5 - 6 levels x 12 bytes) --
+    // two rows cost 1 - 2 % against three (more row builds), tables in global memory 25 %
+    constexpr bool kLdsTab = kLdsRows > 0;
+    static_assert(kLdsRows == 0 || kLdsRows == 3 || (kLdsRows == 2 && kBox), "ring of 3 rows, or 2 for the box instances");
     static_assert(kJump || !kLdsTab, "tables exist for the jump instances only");
     static_assert(kCoarse || !kJump, "the jump instances read the tree's top from the coarse table (no table: depth < 5 or coarse_log2 = 0, where jumps never pay)");
     static_assert(kTuned || kMulti, "the instances with run-time scheduling knobs exist once, with the multi-light code compiled in (it renders one light too)");
@@ -250,6 +253,22 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? (kMulti ? VRC_MIN_BLOCKS_JUM
     // kBox: the descriptor index of every stack level, behind the stack; boxw = the box word of the empty node locate() found
     uint32_t *const lds_own = reinterpret_cast<uint32_t *>(lds_stack + (size_t)(kCoarse ? n - lc : (n > 1 ? n - 1 : 1)) * kBlockThreads);
     uint32_t boxw = 0;
+    // the empty child i of a node with valid mask `valid`, widened over the empty siblings that lie ahead of the ray (enter_node's
+    // rule for the box-less instances), as a box word: extent code 1 -- one node size -- on the side the ray leaves through
+    auto widen_word = [&](unsigned valid, int i) -> uint32_t {
+        const unsigned sgn = ((unsigned)r.flags >> kFlagStepShift) & 7u, ahead = ((unsigned)i ^ sgn) & 7u;
+        auto span = [&](unsigned e) -> unsigned { return ((unsigned)(0xFF5533110F050301ULL >> (8u * e)) & 0xffu) << ((unsigned)i & ~e); };
+        auto pair = [&](unsigned e) -> unsigned { return (1u << i) | (1u << ((unsigned)i ^ e)); };
+        unsigned ext = 0;
+        if ((span(ahead) & valid) == 0) ext = ahead;
+        else if ((ahead & 2u) && (pair(2u) & valid) == 0) ext = 2u;
+        else if ((ahead & 1u) && (pair(1u) & valid) == 0) ext = 1u;
+        else if ((ahead & 4u) && (pair(4u) & valid) == 0) ext = 4u;
+        uint32_t w = 0;
+#pragma unroll
+        for (unsigned a = 0; a < 3; a++) w |= ((ext >> a) & 1u) << (5u * a + (((sgn >> a) & 1u) ? 15u : 0u));
+        return w;
+    };
     auto locate = [&](int x, int y, int z) -> int {
         const unsigned diff = (unsigned)((x ^ pvx) | (y ^ pvy) | (z ^ pvz));
         uint32_t own = 0;                                 // kBox: index of the descriptor `cur` was made from (top >= lc), or the cell's box word (top < lc)
@@ -286,16 +305,22 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? (kMulti ? VRC_MIN_BLOCKS_JUM
                 // (round 5: the box word of the voxel's slot one level down loaded speculatively BESIDE every descriptor, so that it is
                 // never a dependent load of its own: headline 1.510 vs 1.502 ms, 4 lights 3.69 vs 3.63 -- the event chain's latency
                 // is covered by the other waves, the extra load instruction is not)
-                if (kBox) boxw = top < lc ? own : p.boxes[(size_t)own * 8u + (unsigned)i];
+                // (the box word: the table's own for a cell that resolves above its level; the descriptor's record; or, below the levels
+                // that have records -- trees too large for a word per descriptor -- the node widened over its empty siblings, as a word)
+                if (kBox) boxw = top < lc ? own : (top < p.box_levels ? p.boxes[(size_t)own * 8u + (unsigned)i] : widen_word(masks & 0xffu, i));
                 return b;
             }
             if (((masks >> 8) & bit) || b == 0) return -1;
-            const uint64_t child = (cur >> 16) + (uint64_t)(__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1);
+            const unsigned rank = (unsigned)__popc(masks & 0xffu & ((bit << 1) - 1u)) - 1u;
+            const uint64_t child = (cur >> 16) + (uint64_t)rank;
             const uint64_t d = descriptors[child];
+            // the child's box record: the descriptor index itself, or (upper levels only) the parent's first-child record + the rank
+            // -- a load beside the descriptor's, not behind it
+            if (kBox) own = p.box_child ? (top + 1 < p.box_levels ? p.box_child[own] + rank : 0u) : (uint32_t)child;
             c_desc++;
             cur = make_entry(descriptors, child, d);
             lds_stack[(top + 1 - sbase) * kBlockThreads + tid] = cur;   // level top+1 (>= lc + 1 with the table)
-            if (kBox) { own = (uint32_t)child; lds_own[(top + 1 - sbase) * kBlockThreads + tid] = own; }
+            if (kBox) lds_own[(top + 1 - sbase) * kBlockThreads + tid] = own;
             top++;
         }
     };
@@ -381,7 +406,7 @@ __global__ __launch_bounds__(kBlockThreads, kJump ? (kMulti ? VRC_MIN_BLOCKS_JUM
     JumpWord *jtab = nullptr;
     uint32_t jrows = 0;
     // rows in LDS: behind the traversal stack, [ring row][pair][thread], one 8-byte word each (ds_read_b64 / ds_write_b64, consecutive threads)
-    constexpr int kRing = kLdsTab ? VRC_LDS_RING : 4;    // table rows per ray (exact_jump.hpp)
+    constexpr int kRing = kLdsTab ? kLdsRows : 4;        // table rows per ray (exact_jump.hpp)
     const int jstride = kLdsTab ? kBlockThreads : 64;
     if (kLdsTab) jtab = reinterpret_cast<JumpWord *>(lds_own + (kBox ? (size_t)(n - lc) * kBlockThreads : 0)) + tid;   // (8-byte aligned: whole multiples of 1 KB before it)
     else if (kJump && s_jump_slot >= 0) jtab = reinterpret_cast<JumpWord *>(p.jump_cache) + ((size_t)s_jump_slot * kTilesPerBlock + (tid >> 6)) * (size_t)(3 * kRing * 64) + (tid & 63);
@@ -997,36 +1022,42 @@ static size_t svo_stack_bytes(const RaycastParams &p) {
     // (with the boxes: a dword per level and thread for the descriptor index, behind the 8-byte entries)
     return (size_t)levels * kBlockThreads * (sizeof(uint64_t) + (svo_uses_boxes(p) ? sizeof(uint32_t) : 0)) + (size_t)p.lds_pad_bytes;
 }
-constexpr size_t kLdsTabBytes = (size_t)(3 * VRC_LDS_RING) * kBlockThreads * sizeof(JumpWord);   // ring rows x 3 pairs, one 8-byte word per thread
+constexpr size_t lds_table_bytes(int rows) { return (size_t)(3 * rows) * kBlockThreads * sizeof(JumpWord); }   // ring rows x 3 pairs, one 8-byte word per thread
 
-// Do the Euclid tables of this frame live in LDS?  Yes when the jump instance with stack + tables still reaches the blocks
-// per CU its registers allow (VRC_MIN_BLOCKS_JUMP) -- asked of the runtime once per LDS size; setting jump_tables_lds = 0 / 1
-// overrides (2 = this rule).  vrc_api.cpp asks the same question to know whether the global table buffer is needed.
-bool jump_tables_in_lds(const RaycastParams &p) {
-    if (!p.svo || p.stepping_mode != 0 || !svo_uses_coarse(p)) return false;
-    if (p.jump_tables_lds == 0) return false;
-    if (p.jump_tables_lds == 1) return true;
-    const size_t lds = svo_stack_bytes(p) + kLdsTabBytes;
+// How many rows of the jumps' Euclid tables live in LDS for this frame: 3 when the jump instance with stack + tables still reaches
+// the blocks per CU its registers allow (VRC_MIN_BLOCKS_JUMP) -- asked of the runtime once per LDS size -- else 2 (the box instances
+// have a two-row twin for their deeper stacks), else 0: the tables live in global memory.  Setting jump_tables_lds = 0 / 1
+// overrides (never / three rows whatever the occupancy; 2 = this rule).  vrc_api.cpp asks to know whether the global table buffer is needed.
+int jump_tables_lds_rows(const RaycastParams &p) {
+    if (!p.svo || p.stepping_mode != 0 || !svo_uses_coarse(p)) return 0;
+    if (p.jump_tables_lds == 0) return 0;
+    if (p.jump_tables_lds == 1) return 3;
     static std::mutex guard;                             // (handles of several host threads may ask at the same time)
     std::lock_guard<std::mutex> lock(guard);
-    // asked of the instance that will run (single- / multi-light, with / without the table and the boxes) on the current device,
-    // once per (device, instance, LDS size)
-    const bool coarse = svo_uses_coarse(p), box = svo_uses_boxes(p), multi = p.light_count > 1;
+    // asked of the instance that will run (single- / multi-light, with / without the boxes) on the current device, once per
+    // (device, instance, LDS size)
+    const bool box = svo_uses_boxes(p), multi = p.light_count > 1;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const unsigned long long key = ((unsigned long long)lds << 16) | ((unsigned long long)(dev & 0xff) << 8) | (coarse ? 1u : 0u) | (box ? 2u : 0u) | (multi ? 4u : 0u);
+    const size_t stack = svo_stack_bytes(p);
+    const unsigned long long key = ((unsigned long long)stack << 16) | ((unsigned long long)(dev & 0xff) << 8) | (box ? 2u : 0u) | (multi ? 4u : 0u);
     static unsigned long long cached_key[8] = {~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL};
-    static bool cached[8];
-    const int slot = (coarse ? 1 : 0) | (box ? 2 : 0) | (multi ? 4 : 0);
+    static int cached[8];
+    const int slot = (box ? 2 : 0) | (multi ? 4 : 0);
     if (cached_key[slot] != key) {
-        const void *fn = box ? (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, true, true, true>)
-                                      : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, true, true>))
-                             : (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, true, true>)
-                                      : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, true, true>));
-        int per_cu = 0;
-        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlockThreads, lds);
-        (void)hipGetLastError();
-        cached[slot] = e == hipSuccess && per_cu >= (multi ? VRC_MIN_BLOCKS_JUMP_MULTI : VRC_MIN_BLOCKS_JUMP);
+        auto fits = [&](const void *fn, int rows) {
+            int per_cu = 0;
+            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlockThreads, stack + lds_table_bytes(rows));
+            (void)hipGetLastError();
+            return e == hipSuccess && per_cu >= (multi ? VRC_MIN_BLOCKS_JUMP_MULTI : VRC_MIN_BLOCKS_JUMP);
+        };
+        const void *f3 = box ? (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, 3, true, true>)
+                                      : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, 3, true, true>))
+                             : (multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, 3, true>)
+                                      : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, 3, true>));
+        const void *f2 = multi ? reinterpret_cast<const void *>(raycast_svo_kernel<true, true, true, 2, true, true>)
+                               : reinterpret_cast<const void *>(raycast_svo_kernel<true, false, true, 2, true, true>);
+        cached[slot] = fits(f3, 3) ? 3 : (box && fits(f2, 2)) ? 2 : 0;
         cached_key[slot] = key;
     }
     return cached[slot];
@@ -1039,15 +1070,18 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
     if (p.svo && p.stepping_mode == 1) return launch_raycast_jump(p, stream);
     if (p.svo) {
         const bool jump = p.jump_min_run < kJumpOff, multi = p.light_count > 1;
-        const bool lds_tab = jump && p.jump_tables_lds == 1;      // (vrc_api.cpp has resolved the setting to 0 / 1 with jump_tables_in_lds)
-        const size_t lds = svo_stack_bytes(p) + (lds_tab ? kLdsTabBytes : 0);
+        const int lds_rows = jump ? p.jump_tables_lds : 0;       // (vrc_api.cpp has resolved the setting to 0 / 2 / 3 rows with jump_tables_lds_rows)
+        if (lds_rows != 0 && lds_rows != 3 && !(lds_rows == 2 && svo_uses_boxes(p))) return hipErrorInvalidValue;
+        const bool lds_tab = lds_rows > 0;
+        const size_t lds = svo_stack_bytes(p) + lds_table_bytes(lds_rows);
         const bool tuned = (!jump || p.jump_min_run == (lds_tab ? kDefaultJumpMinRunLds : kDefaultJumpMinRun)) &&
                            p.widen_nodes != 0 && p.arith_mask != 0 && p.safe_run != 0 && p.single_step != 0 &&
                            p.shade_threshold == kDefaultShadeThreshold && p.safe_steps == (jump ? kDefaultSafeStepsJump : kDefaultSafeSteps) &&
                            p.exact_steps == kDefaultExactSteps && p.burst_steps == kDefaultBurstSteps;
         if (jump && !lds_tab && (!p.jump_cache || !p.jump_slots || p.jump_slot_count < 1)) return hipErrorInvalidValue;
-        // 21 instances: the knobs at their defaults (kTuned) x {no jumps | Euclid tables in global memory | in LDS} x {no table | coarse
-        // table | + empty boxes} x {one light | multi-light}, jumps only with the table; and the same with run-time knobs ONCE each,
+        // 24 instances: the knobs at their defaults (kTuned) x {no jumps | Euclid tables in global memory | in LDS} x {no table | coarse
+        // table | + empty boxes} x {one light | multi-light}, jumps only with the table, the box instances also with a two-row ring in
+        // LDS (deep trees); and the same with run-time knobs ONCE each,
         // with the multi-light code compiled in (it renders a single light too -- the relight block never runs): those exist for the
         // tests and tools that move the knobs, and a frame rendered through them is the same frame
 #define VRC_LAUNCH(...) hipLaunchKernelGGL((raycast_svo_kernel<__VA_ARGS__>), dim3(nblocks), dim3(kBlockThreads), lds, stream, p)
@@ -1055,15 +1089,16 @@ hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream) {
                                     else VRC_LAUNCH(J, false, true, L, __VA_ARGS__); } while (0)
         if (jump && !svo_uses_coarse(p)) return hipErrorInvalidValue;     // (vrc_api.cpp switches the jumps off where there is no table)
         if (svo_uses_boxes(p)) {
-            if (lds_tab) VRC_LAUNCH_MT(true, true, true, true);
-            else if (jump) VRC_LAUNCH_MT(true, false, true, true);
-            else VRC_LAUNCH_MT(false, false, true, true);
+            if (lds_rows == 3) VRC_LAUNCH_MT(true, 3, true, true);
+            else if (lds_rows == 2) VRC_LAUNCH_MT(true, 2, true, true);
+            else if (jump) VRC_LAUNCH_MT(true, 0, true, true);
+            else VRC_LAUNCH_MT(false, 0, true, true);
         } else if (svo_uses_coarse(p)) {
-            if (lds_tab) VRC_LAUNCH_MT(true, true, true);
-            else if (jump) VRC_LAUNCH_MT(true, false, true);
-            else VRC_LAUNCH_MT(false, false, true);
+            if (lds_tab) VRC_LAUNCH_MT(true, 3, true);
+            else if (jump) VRC_LAUNCH_MT(true, 0, true);
+            else VRC_LAUNCH_MT(false, 0, true);
         } else {
-            VRC_LAUNCH_MT(false, false, false);
+            VRC_LAUNCH_MT(false, 0, false);
         }
 #undef VRC_LAUNCH_MT
 #undef VRC_LAUNCH

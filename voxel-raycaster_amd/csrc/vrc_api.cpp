@@ -27,15 +27,18 @@
 
 namespace vrc {
 hipError_t launch_raycast(const RaycastParams &p, hipStream_t stream);
-bool jump_tables_in_lds(const RaycastParams &p);
+int jump_tables_lds_rows(const RaycastParams &p);
 hipError_t launch_coarse_build(const uint64_t *descriptors, uint64_t root_index, int log2_dim, int lc, uint64_t *out, hipStream_t stream);
 hipError_t launch_box_positions(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, uint64_t *pos, hipStream_t stream);
 hipError_t box_queries_cut(unsigned long long *out);
+struct BoxUpper { uint64_t *desc = nullptr, *pos = nullptr; uint32_t *child = nullptr, *boxes = nullptr; uint64_t count = 0; int levels = 0; };
+hipError_t launch_box_build_upper(const uint64_t *descriptors, uint64_t root_index, int n, int lc, uint64_t max_records, int max_levels,
+                                  BoxUpper *out, uint32_t *aux, hipStream_t stream);
 hipError_t launch_box_build(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, int lc, uint64_t *pos_tmp,
                             uint32_t *boxes, uint32_t *aux, hipStream_t stream);
 hipError_t launch_box_check_cells(const uint64_t *descriptors, uint64_t root_index, int n, int lc, const uint32_t *aux, uint64_t samples,
                                   uint64_t seed, unsigned long long *result, hipStream_t stream);
-hipError_t launch_box_check(const uint64_t *descriptors, uint64_t n_desc, uint64_t root_index, int n, const uint64_t *pos,
+hipError_t launch_box_check(const uint64_t *descriptors, uint64_t n_records, uint64_t root_index, int n, const uint64_t *pos, const uint64_t *desc_of,
                             const uint32_t *boxes, uint64_t samples, uint64_t seed, unsigned long long *result, hipStream_t stream);
 hipError_t launch_frame_setup(const RaycastParams &p, hipStream_t stream);
 hipError_t launch_reduce_counters(const unsigned long long *partials, int nblocks, unsigned long long *out,
@@ -70,6 +73,10 @@ struct vrc_tree {
     uint64_t *d_coarse = nullptr; uint64_t coarse_root = 0; int coarse_depth = 0, coarse_log2 = 0;
     uint32_t *d_boxes = nullptr, *d_box_aux = nullptr; uint64_t box_root = 0; int box_depth = 0, box_log2 = 0; double box_build_seconds = 0.0;
     unsigned long long box_queries_cut = 0;               // region queries of the build that gave up at their budget (boxes smaller than they could be)
+    // box records: one per descriptor (box_mode 1: record = descriptor index) or for the upper levels only (box_mode 2: breadth-first
+    // records, d_box_child = first-child record, d_box_desc / d_box_pos = descriptor and position of a record, kept for the self-check)
+    int box_mode = 0, box_levels = 0, box_fail_mode = 0; int64_t box_levels_asked = 0, box_records_asked = 0; uint64_t box_records = 0;
+    uint32_t *d_box_child = nullptr; uint64_t *d_box_desc = nullptr, *d_box_pos = nullptr;
     // an allocation failed: the frames go on without the structure.  Not retried every frame -- but retried as soon as what was
     // asked for changes (level, root, depth) or the host sets coarse_log2 / empty_boxes again (vrc_setting_add / _set)
     bool coarse_gave_up = false, boxes_gave_up = false;
@@ -83,6 +90,9 @@ struct vrc_tree {
         if (d_coarse) (void)hipFree(d_coarse);
         if (d_boxes) (void)hipFree(d_boxes);
         if (d_box_aux) (void)hipFree(d_box_aux);
+        if (d_box_child) (void)hipFree(d_box_child);
+        if (d_box_desc) (void)hipFree(d_box_desc);
+        if (d_box_pos) (void)hipFree(d_box_pos);
         if (d_desc) (void)hipFree(d_desc);
         if (d_attach_lookup) (void)hipFree(d_attach_lookup);
         if (d_attach) (void)hipFree(d_attach);
@@ -177,6 +187,12 @@ int fail(vrc_caster *h, int code, const char *fmt, ...) {
 template <class T>
 void release(T *&p) {
     if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+// the tree's empty boxes, in either form
+void release_boxes(vrc_tree *t) {
+    release(t->d_boxes); release(t->d_box_aux); release(t->d_box_child); release(t->d_box_desc); release(t->d_box_pos);
+    t->box_log2 = 0; t->box_mode = 0; t->box_records = 0; t->box_levels = 0;
 }
 
 // the handle lets go of its tree; the arrays, the table and the boxes are freed with the last handle that holds them
@@ -1045,7 +1061,7 @@ void derive_from_tree(vrc_caster *h, vrc_tree *t, int log2_dim, uint64_t root_in
     if (lc >= 1 && t->n_desc < (1ULL << 43)) {
         if (!t->d_coarse || t->coarse_log2 != (int)lc || t->coarse_root != root_index || t->coarse_depth != log2_dim) {
             release(t->d_coarse);
-            release(t->d_boxes); release(t->d_box_aux); t->box_log2 = 0;   // (the boxes' parallel word belongs to the table's cells)
+            release_boxes(t);                                      // (the boxes' parallel word belongs to the table's cells)
             t->coarse_log2 = 0;
             const bool failed_before = t->coarse_gave_up && t->coarse_fail_log2 == (int)lc && t->coarse_fail_root == root_index && t->coarse_fail_depth == log2_dim;
             if (!failed_before) {
@@ -1066,30 +1082,62 @@ void derive_from_tree(vrc_caster *h, vrc_tree *t, int log2_dim, uint64_t root_in
         if (t->d_coarse) { p.coarse = t->d_coarse; p.coarse_log2 = (int32_t)lc; }
     } else if (t->d_coarse) {
         release(t->d_coarse); t->coarse_log2 = 0;             // the setting went to "none": the table goes too
-        release(t->d_boxes); release(t->d_box_aux); t->box_log2 = 0;
+        release_boxes(t);
     }
     // the empty boxes (empty_boxes.hip; setting empty_boxes: -1 = when the tree is small enough for them, 0 = never, 1 = always):
     // 32 bytes per descriptor + 4 per table cell, built like the table they hang on; exact mode only.
     // (Words for the table's cells ALONE -- boxes in the coarse space, octree nodes below it -- would fit any tree; measured:
     // depth 12 1.71 ms against 1.50 with all words and 1.91 without, depth 14 -2 %, depth 16 +4 %: not offered.)
+    // Two forms (setting empty_boxes: -1 = by the tree's size, 0 = never, 1 = a word per descriptor and child, 2 = the upper levels only):
+    //   * a word per (descriptor, child): trees of up to 2^29 descriptors (16 GB of words) by default.  Beyond that the words are
+    //     not only expensive -- gathered from an array of tens of GB they miss the TLB as well as the caches (the depth-15 bench
+    //     terrain, 1.4 G descriptors: 4.8 ms with its 45 GB of words, 3.75 without);
+    //   * the upper levels only (round 6): box records for the descriptors of the levels the record budget reaches (setting
+    //     empty_box_records, default 400 M records = 14 GB of words, at most a quarter of the free device memory; setting
+    //     empty_box_levels caps the levels), numbered breadth-first, the nodes below them widened over their empty siblings -- any
+    //     tree, also beyond the 2^31 descriptors a 32-bit descriptor index reaches.
     const int64_t want_boxes = setting_or(h, "empty_boxes", -1);
-    const bool box_ok = p.coarse != nullptr && stepping_mode == 0 && log2_dim <= 19 && t->n_desc < (1ULL << 31);
-    if (box_ok && (want_boxes > 0 || (want_boxes < 0 && t->n_desc <= (1ULL << 28)))) {
-        if (!t->d_boxes || t->box_log2 != (int)lc || t->box_root != root_index || t->box_depth != log2_dim) {
-            release(t->d_boxes); release(t->d_box_aux);
-            t->box_log2 = 0;
-            const bool failed_before = t->boxes_gave_up && t->box_fail_log2 == (int)lc && t->box_fail_root == root_index && t->box_fail_depth == log2_dim;
+    const bool box_ok = p.coarse != nullptr && stepping_mode == 0 && log2_dim <= 19;
+    int box_mode = 0;                                              // 0 none, 1 per descriptor, 2 upper levels
+    if (box_ok && want_boxes == 1 && t->n_desc < (1ULL << 31)) box_mode = 1;
+    else if (box_ok && want_boxes >= 2) box_mode = 2;
+    else if (box_ok && want_boxes < 0) box_mode = t->n_desc <= (1ULL << 29) ? 1 : 2;
+    if (box_mode) {
+        const int64_t want_levels = box_mode == 2 ? std::max<int64_t>(0, setting_or(h, "empty_box_levels", 0)) : 0;
+        const int64_t want_records = box_mode == 2 ? std::max<int64_t>(0, setting_or(h, "empty_box_records", 0)) : 0;
+        if (!t->d_boxes || t->box_mode != box_mode || t->box_levels_asked != want_levels || t->box_records_asked != want_records || t->box_log2 != (int)lc || t->box_root != root_index || t->box_depth != log2_dim) {
+            release_boxes(t);
+            const bool failed_before = t->boxes_gave_up && t->box_fail_log2 == (int)lc && t->box_fail_root == root_index && t->box_fail_depth == log2_dim && t->box_fail_mode == box_mode;
             if (!failed_before) {
                 uint64_t *pos_tmp = nullptr;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 float ms = 0.f;
-                hipError_t e = hipMalloc((void **)&t->d_boxes, sizeof(uint32_t) * 8 * t->n_desc);
-                if (e == hipSuccess) e = hipMalloc((void **)&t->d_box_aux, sizeof(uint32_t) << (3 * lc));
-                if (e == hipSuccess) e = hipMalloc((void **)&pos_tmp, sizeof(uint64_t) * t->n_desc);
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+                hipError_t e = hipMalloc((void **)&t->d_box_aux, sizeof(uint32_t) << (3 * lc));
                 if (e == hipSuccess) e = hipEventCreate(&e0);
                 if (e == hipSuccess) e = hipEventCreate(&e1);
                 if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
-                if (e == hipSuccess) e = vrc::launch_box_build(t->d_desc, t->n_desc, root_index, log2_dim, (int)lc, pos_tmp, t->d_boxes, t->d_box_aux, h->stream);
+                if (box_mode == 1) {
+                    // (an optional structure must not be what makes the next allocation fail: at most half of what is free right now)
+                    if (e == hipSuccess && want_boxes < 0 && t->n_desc > (1ULL << 28) && 40ULL * t->n_desc > free_b / 2) e = hipErrorOutOfMemory;
+                    if (e == hipSuccess) e = hipMalloc((void **)&t->d_boxes, sizeof(uint32_t) * 8 * t->n_desc);
+                    if (e == hipSuccess) e = hipMalloc((void **)&pos_tmp, sizeof(uint64_t) * t->n_desc);
+                    if (e == hipSuccess) e = vrc::launch_box_build(t->d_desc, t->n_desc, root_index, log2_dim, (int)lc, pos_tmp, t->d_boxes, t->d_box_aux, h->stream);
+                    if (e == hipSuccess) { t->box_records = t->n_desc; t->box_levels = log2_dim; }
+                } else {
+                    uint64_t budget = (uint64_t)want_records;
+                    // (measured on the depth-16 terrain, 5.7 G descriptors: 200 M records 4.59 ms, 400 M 4.47, 1.5 G 5.04 -- beyond ~15 GB the
+                    // words themselves become TLB misses; without boxes 4.73)
+                    if (!budget) budget = std::min<uint64_t>(400000000ULL, (uint64_t)(free_b / 4) / 52);
+                    budget = std::min<uint64_t>(budget, 0xffffff00ULL);
+                    vrc::BoxUpper u;
+                    if (e == hipSuccess) e = vrc::launch_box_build_upper(t->d_desc, root_index, log2_dim, (int)lc, std::max<uint64_t>(budget, 9), (int)want_levels, &u, t->d_box_aux, h->stream);
+                    if (e == hipSuccess) {
+                        t->d_boxes = u.boxes; t->d_box_child = u.child; t->d_box_desc = u.desc; t->d_box_pos = u.pos;
+                        t->box_records = u.count; t->box_levels = u.levels;
+                    }
+                }
                 if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
                 if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
@@ -1099,17 +1147,17 @@ void derive_from_tree(vrc_caster *h, vrc_tree *t, int log2_dim, uint64_t root_in
                 if (pos_tmp) (void)hipFree(pos_tmp);
                 if (e != hipSuccess) {
                     (void)hipGetLastError();
-                    release(t->d_boxes); release(t->d_box_aux);
-                    t->boxes_gave_up = true; t->box_fail_log2 = (int)lc; t->box_fail_root = root_index; t->box_fail_depth = log2_dim;
+                    release_boxes(t);
+                    t->boxes_gave_up = true; t->box_fail_log2 = (int)lc; t->box_fail_root = root_index; t->box_fail_depth = log2_dim; t->box_fail_mode = box_mode;
                     t->box_note = std::string("no empty boxes: ") + hipGetErrorString(e) + "; ";
                 } else {
                     t->box_build_seconds = ms * 1e-3;
-                    t->box_log2 = (int)lc; t->box_root = root_index; t->box_depth = log2_dim;
+                    t->box_log2 = (int)lc; t->box_root = root_index; t->box_depth = log2_dim; t->box_mode = box_mode; t->box_levels_asked = want_levels; t->box_records_asked = want_records;
                     t->boxes_gave_up = false; t->box_note.clear();
                 }
             }
         }
-        if (t->d_boxes) { p.boxes = t->d_boxes; p.box_aux = t->d_box_aux; }
+        if (t->d_boxes) { p.boxes = t->d_boxes; p.box_aux = t->d_box_aux; p.box_child = t->d_box_child; p.box_levels = t->box_levels; }
     }
     // (a handle that switches the boxes off keeps them: they belong to the tree, go with it, and a host that toggles the setting
     // between frames -- tests/soak_jumps_gpu.py does -- must not pay the build again and again)
@@ -1253,8 +1301,9 @@ int compute_async_one(vrc_caster *h) {
     // exact closed-form jumps: on from depth 12; the threshold depends on where the Euclid tables live (LDS when stack + tables
     // fit at full occupancy: depth 12)
     p.jump_tables_lds = (int32_t)std::min<int64_t>(2, std::max<int64_t>(0, setting_or(h, "jump_tables_lds", 2)));
-    const bool tables_in_lds = vrc::jump_tables_in_lds(p);
-    p.jump_tables_lds = tables_in_lds ? 1 : 0;                     // resolved once, here: the launch takes it as it is
+    const int lds_rows = vrc::jump_tables_lds_rows(p);             // 3, 2 (deep trees with boxes) or 0 rows of the tables' ring in LDS
+    const bool tables_in_lds = lds_rows > 0;
+    p.jump_tables_lds = lds_rows;                                  // resolved once, here: the launch takes it as it is
     // (the jump instances read the tree's top from the coarse table: without one -- depth < 5, coarse_log2 = 0 -- there are no jumps)
     p.jump_min_run = !p.coarse ? vrc::kJumpOff : (int32_t)std::min<int64_t>(vrc::kJumpOff, std::max<int64_t>(1, setting_or(h, "jump_min_run",
                                     p.log2_dim >= (p.boxes ? vrc::kDefaultJumpMinDepthBoxes : vrc::kDefaultJumpMinDepth) ? (tables_in_lds ? vrc::kDefaultJumpMinRunLds : vrc::kDefaultJumpMinRun)
@@ -1411,10 +1460,14 @@ int vrc_empty_boxes_check(vrc_caster *h, uint64_t samples, uint64_t seed, uint64
     uint64_t *pos = nullptr; unsigned long long *res = nullptr;
     hipError_t e = hipMalloc((void **)&res, 2 * sizeof(unsigned long long));
     unsigned long long out[2] = {0, 0}, cells[2] = {0, 0};
-    if (t->d_boxes) {                                          // the words per (descriptor, child)
+    if (t->d_boxes && t->box_mode == 2) {                      // the records of the upper levels (their descriptors and positions were kept)
+        if (e == hipSuccess) e = vrc::launch_box_check(t->d_desc, t->box_records, t->box_root, t->box_depth, t->d_box_pos, t->d_box_desc, t->d_boxes, samples, seed, res, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, res, sizeof(out), hipMemcpyDeviceToHost);
+    } else if (t->d_boxes) {                                   // the words per (descriptor, child)
         if (e == hipSuccess) e = hipMalloc((void **)&pos, sizeof(uint64_t) * t->n_desc);
         if (e == hipSuccess) e = vrc::launch_box_positions(t->d_desc, t->n_desc, t->box_root, t->box_depth, pos, h->stream);
-        if (e == hipSuccess) e = vrc::launch_box_check(t->d_desc, t->n_desc, t->box_root, t->box_depth, pos, t->d_boxes, samples, seed, res, h->stream);
+        if (e == hipSuccess) e = vrc::launch_box_check(t->d_desc, t->n_desc, t->box_root, t->box_depth, pos, nullptr, t->d_boxes, samples, seed, res, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipMemcpy(out, res, sizeof(out), hipMemcpyDeviceToHost);
     }
@@ -1439,6 +1492,7 @@ int vrc_read_empty_boxes(vrc_caster *h, uint64_t first_descriptor, uint64_t coun
     if (!t) return fail(h, VRC_ERR_NOT_READY, "read_empty_boxes: no octree");
     std::lock_guard<std::mutex> lock(t->guard);
     if (!t->d_boxes) return fail(h, VRC_ERR_NOT_READY, "read_empty_boxes: no boxes (setting empty_boxes, or neither vrc_prepare nor a frame has run yet)");
+    if (t->box_mode != 1) return fail(h, VRC_ERR_NOT_READY, "read_empty_boxes: this tree has box records for its upper levels only (they are not indexed by descriptor)");
     if (first_descriptor > t->n_desc || count > t->n_desc - first_descriptor) return fail(h, VRC_ERR_INVALID_ARGUMENT, "read_empty_boxes: range past the array");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpy(out, t->d_boxes + 8 * first_descriptor, sizeof(uint32_t) * 8 * count, hipMemcpyDeviceToHost));
@@ -1462,7 +1516,9 @@ int vrc_memory_usage2(vrc_caster *h, int32_t rank, vrc_memory2 *out) {
         m.coarse_log2 = t->d_coarse ? t->coarse_log2 : 0;
         m.coarse_bytes = t->d_coarse ? (uint64_t)sizeof(uint64_t) << (3 * t->coarse_log2) : 0;
         m.empty_boxes = q->last_frame_boxes ? 1 : 0;
-        m.box_bytes = (t->d_boxes ? (uint64_t)sizeof(uint32_t) * 8 * t->n_desc : 0) + (t->d_box_aux ? (uint64_t)sizeof(uint32_t) << (3 * t->box_log2) : 0);
+        m.box_bytes = (t->d_boxes ? (uint64_t)t->box_records * (32 + (t->box_mode == 2 ? 20 : 0)) : 0) + (t->d_box_aux ? (uint64_t)sizeof(uint32_t) << (3 * t->box_log2) : 0);
+        m.box_records = t->d_boxes ? t->box_records : 0;
+        m.box_levels = t->d_boxes ? t->box_levels : 0;
         m.box_build_seconds = t->box_build_seconds;
         snprintf(m.note, sizeof(m.note), "%s%s", t->coarse_note.c_str(), t->box_note.c_str());
         m.box_queries_cut = t->d_boxes ? t->box_queries_cut : 0;

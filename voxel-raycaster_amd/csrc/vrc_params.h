@@ -78,11 +78,12 @@ inline uint64_t coarse_index(unsigned cx, unsigned cy, unsigned cz, int lc) {
     const uint64_t brick = (uint64_t)(cx >> k) | ((uint64_t)(cy >> k) << lb) | ((uint64_t)(cz >> k) << (2 * lb));
     return (brick << (3 * k)) | (cx & m) | ((cy & m) << k) | ((cz & m) << (2 * k));
 }
-// the table level for a tree of depth n (0: no table).  From depth 16 on one level finer (1024^3 cells, 8 GB -- vrc_api.cpp only
-// takes it for trees of 0.5 GB and more): the traversal stack then has 6 levels, and stack + Euclid tables of the exact jumps
-// (exact_jump.hpp: 72 bytes per lane) still fit the 128 bytes of LDS a lane has at 5 blocks per CU; with 7 levels the tables
-// would move to global memory (depth 16, 1080p: 6.3 instead of 4.7 ms)
-constexpr int coarse_level_for_depth(int n) { return n >= 16 ? kCoarseMaxLog2 + 1 : n >= 5 ? (n - 2 < kCoarseMaxLog2 ? n - 2 : kCoarseMaxLog2) : 0; }
+// the table level for a tree of depth n (0: no table).  From depth 14 on one level finer (1024^3 cells, 8 GB -- vrc_api.cpp only
+// takes it while the table is at most 16 x the descriptor array): the traversal stack then has 4 (depth 14) to 6 (depth 16) levels,
+// and stack + boxes' index array + Euclid tables of the exact jumps (exact_jump.hpp) still fit the 128 bytes of LDS a lane has at
+// 5 blocks per CU -- with the tables in global memory instead a depth-16 frame takes 6.3 instead of 4.7 ms, and the depth-14 frame
+// WITH boxes 3.16 instead of 2.40
+constexpr int coarse_level_for_depth(int n) { return n >= 14 ? kCoarseMaxLog2 + 1 : n >= 5 ? (n - 2 < kCoarseMaxLog2 ? n - 2 : kCoarseMaxLog2) : 0; }
 
 // hit-record flag bits (include/vrc.h VRC_HIT_FLAG_*)
 constexpr int kFlagWritten = 1, kFlagShadowCast = 2, kFlagShadowHit = 4, kFlagOob = 8;
@@ -173,6 +174,11 @@ struct RaycastParams {
     // above the table's level, or the index of the level-coarse_log2 descriptor).  nullptr: nodes + sibling widening only
     const uint32_t *boxes;
     const uint32_t *box_aux;
+    // boxes for the upper levels only (trees too large for a word per descriptor and child): box records exist for the descriptors of
+    // the levels below box_levels, numbered breadth-first; box_child[record] = the record of the descriptor's first child.  nullptr:
+    // a record per descriptor, record index = descriptor index (then box_levels is the tree's depth)
+    const uint32_t *box_child;
+    int32_t box_levels;
     unsigned long long *counters;
     // host-mapped flag the round watchdog raises (checked by vrc_sync: a truncated frame never looks like success)
     unsigned int *watchdog_flag;
