@@ -221,8 +221,10 @@ def kernel_instance(c, sc, lights) -> str:
     """The template instance vrc_api.cpp / raycast_kernel.hip launch_raycast picks for this caster's default settings."""
     m = c.memory_usage2()
     jump = m["coarse_log2"] > 0 and sc["depth"] >= (11 if m["empty_boxes"] else 12)      # (the jump instances need the coarse table)
-    flags = [jump, lights > 1, True, jump, m["coarse_log2"] > 0, bool(m["empty_boxes"])]
-    return "raycast_svo_kernel<" + ", ".join("true" if f else "false" for f in flags) + ">  (kJump, kMulti, kTuned, kLdsTab, kCoarse, kBox)"
+    levels = sc["depth"] - m["coarse_log2"]                  # stack levels; the boxes add their index array (tools/spill_map.py names the instances)
+    rows = 0 if not jump else (3 if levels * (12 if m["empty_boxes"] else 8) + 72 <= 124 else (2 if m["empty_boxes"] and levels * 12 + 48 <= 124 else 0))
+    flags = ["true" if jump else "false", "true" if lights > 1 else "false", "true", str(rows), "true" if m["coarse_log2"] > 0 else "false", "true" if m["empty_boxes"] else "false"]
+    return "raycast_svo_kernel<" + ", ".join(flags) + ">  (kJump, kMulti, kTuned, kLdsRows, kCoarse, kBox)"
 
 
 def tree_state(c, first_frame_ms=None, warm_frame_ms=None) -> dict:

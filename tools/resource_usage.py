@@ -23,11 +23,12 @@ for src in ("raycast_kernel.hip", "raycast_jump_kernel.hip", "svo_builder_gpu.hi
         elif cur is not None:
             cur[k.split(" [")[0]] = v
 print("# kernel resource usage, gfx950 (hipcc " + " ".join(f for f in g.HIP_FLAGS if f.startswith("-O") or f.startswith("-f")) + ")")
-print("# raycast_svo_kernel<kJump, kMulti, kTuned, kLdsTab, kCoarse>: kJump = exact closed-form jumps compiled in (96 VGPRs: 5 blocks per CU; the")
-print("# others 80: 6), kMulti = multi-light extension, kTuned = scheduling knobs at their defaults (compile-time constants), kLdsTab = the jumps'")
-print("# Euclid tables in LDS (12 KB of dynamic LDS per block), kCoarse = the tree's top from the dense table (the traversal stack then holds the")
-print("# levels below it only: (log2 dim - coarse_log2) * 2 KB of dynamic LDS per block instead of (log2 dim - 1) * 2 KB).  Static LDS only.")
-print("# raycast_jump_kernel<kMulti, kCoarse> = mode B.  The headline instance is raycast_svo_kernel<true, false, true, true, true>.")
+print("# raycast_svo_kernel<kJump, kMulti, kTuned, kLdsRows, kCoarse, kBox>: kJump = exact closed-form jumps compiled in (96 VGPRs: 5 blocks per")
+print("# CU; the others 80: 6), kMulti = multi-light extension, kTuned = scheduling knobs at their defaults (compile-time constants; the")
+print("# run-time twins exist once each, with the multi-light code), kLdsRows = rows of the jumps' Euclid-table ring in LDS (3, or 2 beside the")
+print("# deeper stacks of the box instances; 0 = the tables live in global memory), kCoarse = the tree's top from the dense table, kBox = empty")
+print("# boxes.  Scratch: where it is EXECUTED is what counts -- tools/spill_map.py; the headline instance <true, false, true, 3, true, true> has none.")
+print("# raycast_jump_kernel<kMulti, kCoarse> = mode B.  Static LDS only.")
 print("| kernel | file | VGPRs | SGPRs | scratch B/lane | waves/SIMD | static LDS B |")
 print("|---|---|---|---|---|---|---|")
 for r in rows:

@@ -48,6 +48,6 @@ if __name__ == "__main__":
         rows = spill_map(text, w)
         if rows is None:
             print(w, "not found"); continue
-        print(f"raycast_svo_kernel<{w}> (kJump, kMulti, kTuned, kLdsTab, kCoarse, kBox): phase, scratch loads, scratch stores, other instructions (static)")
+        print(f"raycast_svo_kernel<{w}> (kJump, kMulti, kTuned, kLdsRows, kCoarse, kBox): phase, scratch loads, scratch stores, other instructions (static)")
         for ph, r in rows.items():
             print(f"  {ph:18s} {r[0]:4d} {r[1]:4d} {r[2]:6d}" + ("   <-- hot phase" if ph in HOT_PHASES and (r[0] or r[1]) else ""))

@@ -30,7 +30,7 @@ open(P(f"{rnd}_kernel_stats.txt"), "w").write(
     + "\n# bench.py JSON line of the un-profiled run in the same gpurun call\n" + line + "\n")
 txt0, v0 = pmc(g("pmc_mode0_summary.txt"))
 txt1, v1 = pmc(g("pmc_mode1_summary.txt"))
-for name, txt, v, kern in ((f"{rnd}_pmc_exact.txt", txt0, v0, "raycast_svo_kernel<true, false, true, true, true, true> (exact mode: closed-form jumps, Euclid tables in LDS, coarse table, empty boxes -- the headline kernel)"), (f"{rnd}_pmc_mode_b.txt", txt1, v1, "raycast_jump_kernel<false>")):
+for name, txt, v, kern in ((f"{rnd}_pmc_exact.txt", txt0, v0, "raycast_svo_kernel<true, false, true, 3, true, true> (exact mode: closed-form jumps, Euclid tables in LDS, coarse table, empty boxes -- the headline kernel)"), (f"{rnd}_pmc_mode_b.txt", txt1, v1, "raycast_jump_kernel<false>")):
     util = v["SQ_THREAD_CYCLES_VALU"] / (64 * v["SQ_ACTIVE_INST_VALU"])
     hbm = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
     open(P(name), "w").write(
@@ -113,7 +113,7 @@ hbm = int((2 * v0["FETCH_SIZE"] + v0["WRITE_SIZE"]) * 1024)
 json.dump({"kernel_source_hash": bench.kernel_source_hash(), "hbm_bytes_per_launch": hbm, "fetch_size_kib_raw": v0["FETCH_SIZE"],
            "write_size_kib_raw": v0["WRITE_SIZE"],
            "correction": "gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md HBM section: rocprofv3 reports half of wide coalesced reads; applied to all reads = upper bound), WRITE_SIZE as reported",
-           "source": f"profiles/{rnd}_pmc_exact.txt (separate --pmc passes, kernel raycast_svo_kernel<true, false, true, true, true, true>, headline workload)",
+           "source": f"profiles/{rnd}_pmc_exact.txt (separate --pmc passes, kernel raycast_svo_kernel<true, false, true, 3, true, true>, headline workload)",
            "valu_insts_per_launch": int(v0["SQ_INSTS_VALU"]), "valu_source": f"SQ_INSTS_VALU, profiles/{rnd}_pmc_exact.txt",
            "valu_time_weighted": tw,
            "mode_b": {"hbm_bytes_per_launch": int((2 * v1["FETCH_SIZE"] + v1["WRITE_SIZE"]) * 1024), "valu_insts_per_launch": int(v1["SQ_INSTS_VALU"]),
