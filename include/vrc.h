@@ -188,7 +188,8 @@ int vrc_setting_get(vrc_caster *h, const char *name, int64_t *value);
 int vrc_validate(vrc_caster *h);
 /* Builds what the SVO kernels derive from the tree for the current settings -- the dense table of the tree's top (setting
  * coarse_log2) and the empty boxes (setting empty_boxes): 15 ms + 0.6 s for the 20 M descriptors of a 4096^3 terrain,
- * 2.6 s at 8192^3 -- so that no frame has to.  Needs the octree and the settings octree_dimensions / using_octree;
+ * 2.6 s at 8192^3, 10 s for the 345 M descriptors of a 16384^3 terrain or the 400 M box records of a deeper one -- so that no
+ * frame has to.  Needs the octree and the settings octree_dimensions / using_octree;
  * vrc_validate calls it.  Both structures are optional: a failed allocation is not an error (the frames are rendered by the
  * kernels without them, vrc_memory_usage2().note says why).  A vrc_compute that finds them missing or built for other
  * settings (root, depth, level changed after validate) still builds them itself, synchronously, inside that call -- also
