@@ -159,10 +159,10 @@ int vrc_assign_lights(vrc_caster *h, const float *packed, const int32_t *light_c
  *   octree_bias (1: the :353-354 term as in the reference; 0: without it)
  *   hit_records (1: the 8 x int32 record per pixel behind vrc_read_hits; 0: none -- the reference has none)
  *   stepping_mode (0: exact per-voxel DDA, bit-identical to the array branch; 1: node-exit jumps, DESIGN.md "mode B")
- *   coarse_log2 (-1: by depth = min(depth - 2, 9) from depth 5; 0: none; k: 2^k cells per axis, at most min(depth - 2, 10)):
- *     the levels of the tree above level k as a dense table in HBM, built on the device from the descriptor array at the first
- *     vrc_compute after a tree is assigned (8 << 3k bytes: 1 GB at k = 9).  Both SVO kernels read it instead of descending
- *     from the root; frames, hit records and the exact mode's counters are the same with and without it
+ *   coarse_log2 (-1: by depth = min(depth - 2, 9) from depth 5, 10 from depth 14; 0: none; k: 2^k cells per axis, at most
+ *     min(depth - 2, 10)): the levels of the tree above level k as a dense table in HBM (8 << 3k bytes: 1 GB at k = 9), built on
+ *     the device from the descriptor array by vrc_prepare / vrc_validate (or by the first vrc_compute that finds it missing).
+ *     Both SVO kernels read it instead of descending from the root; frames, hit records and the exact mode's counters are the same with and without it
  *   empty_boxes (-1: by the tree's size; 0: never -- the canonical traversal, canonical read counts; 1: a box word per descriptor and
  *     child, trees below 2^31 descriptors; 2: box records for the upper levels only -- any tree): an empty node is widened to the
  *     empty box a device-side pass over the descriptor array found around it (vrc_prepare builds the words); frames and hit

@@ -45,6 +45,8 @@ def test_empty_boxes_never_change_the_frame(depth, lights, w, h):
     assert chk["boxes_sampled"] > 100000 and chk["solid_voxels"] == 0
     m = c.memory_usage2()
     assert m["empty_boxes"] == 1 and m["box_bytes"] > 32 * sc["octree"].descriptor_buffer.size and m["note"] == ""
+    # a word per descriptor: every level has records; no region query of the build ran into its budget (the counter exists)
+    assert m["box_levels"] == depth and m["box_records"] == sc["octree"].descriptor_buffer.size and m["box_queries_cut"] == 0
     print(f"\ndepth {depth}: boxes built in {chk['build_seconds'] * 1e3:.0f} ms, {m['box_bytes'] / 1e6:.0f} MB; descriptor reads "
           f"{ref[2]['descriptor_reads'] / 1e6:.2f} M canonical, {ctr['descriptor_reads'] / 1e6:.2f} M with the boxes")
     # back to the canonical traversal on the same handle: the canonical count again
