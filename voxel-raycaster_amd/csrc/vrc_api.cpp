@@ -229,10 +229,11 @@ int64_t setting_or(const vrc_caster *h, const char *name, int64_t dflt) {
     return i < 0 ? dflt : h->settings[i].value;
 }
 
-// coarse_log2 / empty_boxes set (again) by the host: a build that failed before -- a transient out-of-memory, a level asked too
+// coarse_log2 / empty_boxes / empty_box_records / empty_box_levels set (again) by the host: a build that failed before -- a transient out-of-memory, a level asked too
 // large -- is tried again by the next vrc_prepare / frame
 void retry_derived(vrc_caster *h, const char *name) {
-    if (!h->tree || (strcmp(name, "coarse_log2") != 0 && strcmp(name, "empty_boxes") != 0)) return;
+    if (!h->tree || (strcmp(name, "coarse_log2") != 0 && strcmp(name, "empty_boxes") != 0 && strcmp(name, "empty_box_records") != 0 &&
+                     strcmp(name, "empty_box_levels") != 0)) return;
     std::lock_guard<std::mutex> lock(h->tree->guard);
     h->tree->coarse_gave_up = h->tree->boxes_gave_up = false;
 }
